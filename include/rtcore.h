@@ -1,0 +1,253 @@
+/*
+ * rtcore.h -- C ABI of the MI355X path-tracing core (librtcore.so).
+ *
+ * The core replaces the CPU hot path of Teetlez/Rust-Raytracer behind plain C
+ * entry points: closest-hit BVH traversal over spheres, axis boxes, rotated
+ * boxes, triangles and meshes, the bounce loop with the four scatter models,
+ * and the environment lookup.  Everything is float32; buffers are row-major,
+ * top image row first, exactly as the reference's `Vec<Vec3>` frame buffers.
+ *
+ * The reference has no FFI of its own.  Each entry point names the Rust item a
+ * host-side `extern "C"` block would call it in place of (file:line relative to
+ * the reference repository root).
+ *
+ * Conventions
+ *   - every function returns RT_OK (0) or a negative RtStatus; nothing throws
+ *     or aborts across this boundary; rt_last_error() gives the message of the
+ *     last failure on the calling thread;
+ *   - the caller owns every buffer it passes; the core copies what it keeps;
+ *   - a scene is immutable after rt_scene_create (the reference shares its
+ *     world as Arc<Bvh>, src/render.rs:155);
+ *   - one host thread drives one scene at a time; a scene lives on the HIP
+ *     device that was current when it was created;
+ *   - "_device" variants take device pointers and a hipStream_t (as void*) and
+ *     never synchronise with the host; the others take host pointers, copy and
+ *     synchronise.
+ *
+ * prim_id: the reference's HitRecord carries no primitive identity
+ * (src/tracer/hittable.rs:13-19).  Here a primitive id is the index in scene
+ * declaration order: object i of RtSceneDesc::objects contributes one id, except
+ * a mesh object, which contributes one id per face, in face order.  Ids are
+ * assigned in object order with no gaps; -1 means "no hit".
+ */
+#ifndef RTCORE_H
+#define RTCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum RtStatus {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_OUT_OF_MEMORY = -2,
+    RT_ERR_DEVICE = -3,      /* a HIP call failed or no device is usable */
+    RT_ERR_EMPTY_SCENE = -4, /* the reference panics on an empty world (src/tracer/bvh.rs:45) */
+    RT_ERR_INTERNAL = -5
+} RtStatus;
+
+/* ---- materials: src/material.rs:138-144, constructors :147-174 ---- */
+typedef enum RtMaterialType {
+    RT_MAT_DIELECTRIC = 0, /* albedo = absorption, p0 = refractive_index, p1 = roughness */
+    RT_MAT_LAMBERTIAN = 1, /* albedo */
+    RT_MAT_METAL = 2,      /* albedo, p0 = roughness */
+    RT_MAT_GLOSSY = 3      /* albedo, p0 = reflectance, p1 = roughness */
+} RtMaterialType;
+
+typedef struct RtMaterial {
+    int32_t type; /* RtMaterialType */
+    float albedo[3];
+    float p0;
+    float p1;
+} RtMaterial;
+
+/* ---- objects: the reference's Hittable implementors (src/tracer/) ---- */
+typedef enum RtObjectType {
+    RT_OBJ_SPHERE = 0,   /* Sphere::new(center, radius, mat)        src/tracer/sphere.rs:18 */
+    RT_OBJ_ABOX = 1,     /* ABox::new(center, size, mat)            src/tracer/cube.rs:20   */
+    RT_OBJ_CUBE = 2,     /* Cube::new(center, size, rotation, mat)  src/tracer/cube.rs:90   */
+    RT_OBJ_TRIANGLE = 3, /* Triangle::new(vertices, normals, two_sided, mat) src/tracer/triangle.rs:21 */
+    RT_OBJ_MESH = 4      /* Mesh::new(polygons, translation, scale, rotation, cull, mat) src/tracer/mesh.rs:22 */
+} RtObjectType;
+
+/*
+ * One scene object.  Field use by type:
+ *   SPHERE   a = center, b[0] = radius
+ *   ABOX     a = center, b = size (any negative component makes the box hollow)
+ *   CUBE     a = center, b = size, c = rotation in units of pi, as the scene file
+ *            gives it (Cube::new multiplies by pi itself, src/tracer/cube.rs:99)
+ *   TRIANGLE tri_vertices / tri_normals (3x3 each), flag = two_sided
+ *   MESH     mesh = index into RtSceneDesc::meshes
+ */
+typedef struct RtObject {
+    int32_t type;     /* RtObjectType */
+    int32_t material; /* index into RtSceneDesc::materials */
+    float a[3];
+    float b[3];
+    float c[3];
+    float tri_vertices[9];
+    float tri_normals[9];
+    int32_t flag;
+    int32_t mesh;
+} RtObject;
+
+/*
+ * One triangle mesh = one tobj model as Mesh::new receives it
+ * (src/io.rs:175-184, src/tracer/mesh.rs:22-87): unified indexing, three
+ * indices per face, a normal for every position.  `rotation` is in radians,
+ * i.e. already multiplied by pi as src/io.rs:180 does.  The core applies
+ * v' = rot(v * scale) + translation and n' = rot(n) itself.
+ */
+typedef struct RtMesh {
+    const float *positions; /* 3 * n_vertices */
+    const float *normals;   /* 3 * n_vertices */
+    const uint32_t *indices; /* 3 * n_faces */
+    uint64_t n_vertices;
+    uint64_t n_faces;
+    float translation[3];
+    float scale[3];
+    float rotation[3];
+    int32_t cull_backface; /* Triangle::two_sided = !cull_backface (src/tracer/mesh.rs:78) */
+    int32_t reserved;
+} RtMesh;
+
+/* Camera::new arguments (src/camera.rs:21-29); vup is fixed to +y as in src/io.rs:198. */
+typedef struct RtCamera {
+    float eye[3];
+    float lookat[3];
+    float vup[3];
+    float fov_degrees;
+    float aperture;
+    float focus_dist;
+} RtCamera;
+
+/* radiant::Image as the renderer reads it (src/render.rs:87-104): row 0 is "up". */
+typedef struct RtEnvMap {
+    const float *rgb; /* width * height * 3, NULL = procedural gradient sky */
+    uint32_t width;
+    uint32_t height;
+} RtEnvMap;
+
+typedef struct RtSceneDesc {
+    const RtMaterial *materials;
+    uint64_t n_materials;
+    const RtObject *objects;
+    uint64_t n_objects;
+    const RtMesh *meshes;
+    uint64_t n_meshes;
+    RtCamera camera;
+    RtEnvMap env;
+} RtSceneDesc;
+
+typedef struct RtScene RtScene; /* opaque */
+
+/* Renderer::render / Renderer::preview modes (src/render.rs:31-36). */
+typedef enum RtMode { RT_MODE_NORMALS = 0, RT_MODE_COLORS = 1, RT_MODE_IMAGE = 2 } RtMode;
+
+/*
+ * The Renderer fields that are not part of the world (src/render.rs:151-160)
+ * plus what replaces the reference's unseeded generators: every random number
+ * is a pure function of (seed, pixel, pass_index * samples + sample, bounce,
+ * dimension), so a pass gives the same image on any device count.
+ */
+typedef struct RtRenderParams {
+    uint32_t width;
+    uint32_t height;
+    uint32_t samples;     /* Renderer::sample_rate */
+    uint32_t max_bounce;  /* Renderer::max_bounce */
+    float light_clamp;    /* Renderer::light_clamp; INFINITY = no clamp */
+    int32_t mode;         /* RtMode */
+    uint32_t pass_index;  /* global index of this pass (0-based) */
+    uint32_t seed;
+    uint64_t batch_paths; /* paths in flight per wavefront batch; 0 = default */
+} RtRenderParams;
+
+typedef struct RtSceneInfo {
+    uint64_t n_primitives;
+    uint64_t n_triangles;
+    uint64_t n_wide_nodes;
+    uint64_t n_binary_nodes; /* nodes of the reference-shaped tree the wide tree was collapsed from */
+    uint32_t wide_depth;
+    uint32_t node_bytes;      /* bytes of one wide node */
+    uint32_t primitive_bytes; /* bytes of one primitive record */
+    uint32_t reserved;
+    uint64_t device_bytes; /* HBM held by the scene */
+    float bounds_min[3];
+    float bounds_max[3];
+} RtSceneInfo;
+
+/* Counters of the last render pass / closest-hit batch on a scene. */
+typedef struct RtStats {
+    uint64_t rays;        /* Bvh::hit invocations: primary rays + every continued bounce */
+    uint64_t paths;       /* camera paths started */
+    uint64_t node_visits; /* only filled by the *_counted entry points, else 0 */
+    uint64_t prim_tests;
+    double extend_ms; /* device time in the closest-hit stage, when timing was requested */
+    double shade_ms;
+    double other_ms;
+} RtStats;
+
+/* Library / device bring-up.  device < 0 keeps the current HIP device. */
+int rt_init(int device);
+const char *rt_last_error(void);
+const char *rt_version(void);
+
+/*
+ * Builds the world.  Replaces io::load_scene's object loop + Bvh::new
+ * (src/io.rs:112-190, src/tracer/bvh.rs:39-81) and Camera::new
+ * (src/camera.rs:21-50; aspect ratio comes from RtRenderParams at render time,
+ * as src/io.rs:200 takes it from the arguments).
+ */
+int rt_scene_create(const RtSceneDesc *desc, RtScene **out);
+int rt_scene_destroy(RtScene *scene);
+int rt_scene_info(const RtScene *scene, RtSceneInfo *info);
+int rt_scene_stats(const RtScene *scene, RtStats *stats);
+
+/*
+ * One pass: accum[p] += (sum over `samples` of radiance) / samples for every
+ * pixel p.  Replaces Renderer::render(&self, buffer, mode) (src/render.rs:162),
+ * called once per pass from src/main.rs:262.  `accum_rgb` is width*height*3
+ * floats, in/out.
+ */
+int rt_render_pass(RtScene *scene, const RtRenderParams *params, float *accum_rgb);
+int rt_render_pass_device(RtScene *scene, const RtRenderParams *params, float *d_accum_rgb,
+                          void *stream);
+
+/* Renderer::preview(&self, mode) (src/render.rs:222): 1 sample, no bounce; out is overwritten. */
+int rt_preview(RtScene *scene, const RtRenderParams *params, float *out_rgb);
+int rt_preview_device(RtScene *scene, const RtRenderParams *params, float *d_out_rgb, void *stream);
+
+/*
+ * <Bvh as Hittable>::hit(&self, &Ray, t_min, t_max) (src/tracer/bvh.rs:143) on a
+ * batch.  org_dir holds n rays as 6 floats (origin, direction); directions are
+ * normalised on entry as Ray::new does (src/ray.rs:10-15).  Outputs (any may be
+ * NULL): prim_id[n] (-1 = miss), t[n], normal[3n], point[3n]; t/normal/point of
+ * a miss are 0.
+ */
+int rt_closest_hit_batch(RtScene *scene, const float *org_dir, float t_min, float t_max, size_t n,
+                         int32_t *prim_id, float *t, float *normal, float *point);
+int rt_closest_hit_batch_device(RtScene *scene, const float *d_org_dir, float t_min, float t_max,
+                                size_t n, int32_t *d_prim_id, float *d_t, float *d_normal,
+                                float *d_point, void *stream);
+/* Same result; additionally counts node visits and primitive tests into RtStats (slower). */
+int rt_closest_hit_batch_counted_device(RtScene *scene, const float *d_org_dir, float t_min,
+                                        float t_max, size_t n, int32_t *d_prim_id, float *d_t,
+                                        float *d_normal, float *d_point, void *stream);
+
+/* When nonzero, render passes time their stages with HIP events into RtStats (adds syncs). */
+int rt_set_stage_timing(RtScene *scene, int enabled);
+
+/*
+ * Host-side helpers that need no device: the reference's display transform,
+ * kept here so a host without the Rust crate can drain the core.
+ * to_rgb(&Vec3, gamma) -> 0xFFRRGGBB (src/render.rs:39-55).
+ */
+uint32_t rt_to_rgb(const float rgb[3], float inv_gamma);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTCORE_H */

@@ -1,0 +1,307 @@
+// rt_traverse.hpp -- closest-hit traversal of the 4-wide tree, one ray per lane.
+//
+// What must equal the reference (src/tracer/bvh.rs:142-161): the primitive it
+// returns and that primitive's t.  The reference visits right-then-left and hands
+// the left subtree t_max = right hit's t, so among candidates at exactly the same
+// distance the outcome depends on the order of visits and on whether a
+// primitive's own bound check accepts t == t_max:
+//     triangle            t_min <= t <= t_max      accepts a tie  (src/tracer/triangle.rs:64)
+//     box, entry face     t_near <= t_max          accepts a tie  (src/tracer/cube.rs:47-51)
+//     box, exit face      t_far  <  t_max          rejects a tie  (src/tracer/cube.rs:52)
+//     sphere              t_min <  t <  t_max      rejects a tie  (src/tracer/sphere.rs:36,47)
+// Primitives are stored in the reference's visit order, so "visited later" is
+// "has the larger index".  A candidate c replaces the current best b when
+//     c.t < b.t,  or  c.t == b.t and (c.index > b.index ? c accepts ties : !(b accepts ties)).
+// With that rule any traversal order gives the reference's answer, and this
+// traversal goes front to back and culls with the current best distance.
+//
+// Box tests use the reference's formula (src/tracer/cube.rs:163-171) verbatim:
+// t0 = (min - o) * (1/d), t1 = (max - o) * (1/d), hit iff
+// max(max3(min(t0,t1)), t_min) <= min(min3(max(t0,t1)), t_max), with NaN-ignoring
+// min/max.  The formula is monotone in the box, so skipping the reference's
+// interior boxes that the wide nodes swallowed cannot change which leaves are
+// reached; the box that guards each leaf slot is the one the reference tests last
+// before that leaf.
+#ifndef RT_TRAVERSE_HPP
+#define RT_TRAVERSE_HPP
+
+#include "rt_device.hpp"
+
+namespace rtd {
+
+struct Best {
+    float t;
+    int32_t index;  // visit rank = index into the primitive array, -1 = none
+    float u, v;     // barycentrics when the best is a triangle
+    bool ties;      // does the best primitive's own bound check accept t == t_max
+};
+
+RT_DEV void consider(Best &b, float t, bool ties, int32_t index, float u, float v) {
+    bool closer = (t < b.t) || (t == b.t && ((index > b.index) ? ties : !b.ties));
+    if (closer) {
+        b.t = t;
+        b.index = index;
+        b.u = u;
+        b.v = v;
+        b.ties = ties;
+    }
+}
+
+// ABox::hit without the normal (src/tracer/cube.rs:42-56): candidate t and whether it is the entry face
+RT_DEV bool abox_candidate(F3 lo, F3 hi, const Ray &ray, float t_min, float t_max, float *t_out, bool *entry) {
+    F3 inv = f3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    F3 t0 = (lo - ray.o) * inv;
+    F3 t1 = (hi - ray.o) * inv;
+    float t_near = fmaxf(max3(f3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z))), t_min);
+    float t_far = fminf(min3(f3(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z))), t_max);
+    if (t_near <= t_far) {
+        if (t_near > t_min) {
+            *t_out = t_near;
+            *entry = true;
+            return true;
+        }
+        if (t_far < t_max) {
+            *t_out = t_far;
+            *entry = false;
+            return true;
+        }
+    }
+    return false;
+}
+// the face-matching normal of ABox::hit (src/tracer/cube.rs:57-66)
+RT_DEV F3 abox_normal(F3 lo, F3 hi, F3 p, bool hollow) {
+    F3 n;
+    if (fabsf(p.x - hi.x) < kBoxTolerance)
+        n = f3(1.0f, 0.0f, 0.0f);
+    else if (fabsf(p.y - hi.y) < kBoxTolerance)
+        n = f3(0.0f, 1.0f, 0.0f);
+    else if (fabsf(p.z - hi.z) < kBoxTolerance)
+        n = f3(0.0f, 0.0f, 1.0f);
+    else if (fabsf(p.x - lo.x) < kBoxTolerance)
+        n = -f3(1.0f, 0.0f, 0.0f);
+    else if (fabsf(p.y - lo.y) < kBoxTolerance)
+        n = -f3(0.0f, 1.0f, 0.0f);
+    else if (fabsf(p.z - lo.z) < kBoxTolerance)
+        n = -f3(0.0f, 0.0f, 1.0f);
+    else
+        n = f3(0.0f, 0.0f, 0.0f);
+    return n * (hollow ? -1.0f : 1.0f);
+}
+// the local ray of Cube::hit (src/tracer/cube.rs:107-111)
+RT_DEV Ray cube_local_ray(F3 center, Rotor rot, const Ray &ray) {
+    Rotor rev = reversed(rot);
+    Ray l;
+    l.o = rotate(rev, ray.o - center) + center;
+    l.d = normalized(rotate(rev, ray.d));
+    return l;
+}
+
+// Tests the primitive at `index` and offers its candidate to `best`.  t_max is the ray's own bound.
+RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, const Ray &ray, float t_min, float t_max,
+                           Best &best) {
+    const float4 *r = prims + (size_t)index * RT_PRIM_FLOAT4S;
+    float4 r0 = r[0], r1 = r[1], r2 = r[2];
+    uint32_t meta = __float_as_uint(r2.z);
+    uint32_t type = meta & RT_PRIM_TYPE_MASK;
+    bool flag = (meta & RT_PRIM_FLAG) != 0;
+    if (type == RT_PRIM_TRIANGLE) {
+        // Triangle::hit (src/tracer/triangle.rs:37-66); e1, e2 are stored, they are the same floats
+        F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
+        F3 h = cross(ray.d, e2);
+        float a = dot(e1, h);
+        if ((!flag && (__float_as_uint(a) >> 31)) || fabsf(a) < 1e-6f) return;
+        float f = 1.0f / a;
+        F3 s = ray.o - v0;
+        float u = f * dot(s, h);
+        if (!(u >= 0.0f && u <= 1.0f)) return;
+        F3 q = cross(s, e1);
+        float v = f * dot(ray.d, q);
+        if (v < 0.0f || u + v > 1.0f) return;
+        float t = f * dot(e2, q);
+        if (t < t_min || t > t_max) return;
+        consider(best, t, true, index, u, v);
+    } else if (type == RT_PRIM_SPHERE) {
+        // Sphere::hit (src/tracer/sphere.rs:28-58)
+        F3 c = f3(r0.x, r0.y, r0.z);
+        float radius = r0.w;
+        F3 oc = ray.o - c;
+        float half_b = dot(oc, ray.d);
+        float disc = half_b * half_b - (mag_sq(oc) - (radius * radius));
+        if (disc > 0.0f) {
+            float h = sqrtf(disc);
+            float temp = -half_b - h;
+            if (temp < t_max && temp > t_min) {
+                consider(best, temp, false, index, 0.0f, 0.0f);
+                return;
+            }
+            temp = -half_b + h;
+            if (temp < t_max && temp > t_min) consider(best, temp, false, index, 0.0f, 0.0f);
+        }
+    } else if (type == RT_PRIM_ABOX) {
+        F3 lo = f3(r0.x, r0.y, r0.z), hi = f3(r0.w, r1.x, r1.y);
+        float t;
+        bool entry;
+        if (abox_candidate(lo, hi, ray, t_min, t_max, &t, &entry)) consider(best, t, entry, index, 0.0f, 0.0f);
+    } else {
+        F3 center = f3(r0.x, r0.y, r0.z), half = f3(r0.w, r1.x, r1.y);
+        Rotor rot{r1.z, r1.w, r2.x, r2.y};
+        Ray local = cube_local_ray(center, rot, ray);
+        float t;
+        bool entry;
+        if (abox_candidate(center - half, center + half, local, t_min, t_max, &t, &entry))
+            consider(best, t, entry, index, 0.0f, 0.0f);
+    }
+}
+
+// HitRecord fields of the winning primitive: normal, material, primitive id.
+RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, const Best &best, F3 *normal, uint32_t *material,
+                       int32_t *prim_id) {
+    const float4 *r = (const float4 *)sc.prims + (size_t)best.index * RT_PRIM_FLOAT4S;
+    float4 r0 = r[0], r1 = r[1], r2 = r[2];
+    uint32_t meta = __float_as_uint(r2.z);
+    uint32_t type = meta & RT_PRIM_TYPE_MASK;
+    bool flag = (meta & RT_PRIM_FLAG) != 0;
+    *material = meta >> RT_PRIM_MAT_SHIFT;
+    *prim_id = (int32_t)__float_as_uint(r2.w);
+    if (type == RT_PRIM_TRIANGLE) {
+        // src/tracer/triangle.rs:68-70
+        const float4 *nn = (const float4 *)sc.tri_normals + (size_t)best.index * 3;
+        float4 a = nn[0], b = nn[1], c = nn[2];
+        F3 n0 = f3(a.x, a.y, a.z), n1 = f3(b.x, b.y, b.z), n2 = f3(c.x, c.y, c.z);
+        *normal = normalized((1.0f - (best.u + best.v)) * n0 + best.u * n1 + best.v * n2);
+    } else if (type == RT_PRIM_SPHERE) {
+        F3 p = ray_at(ray, best.t);
+        *normal = normalized(p - f3(r0.x, r0.y, r0.z));
+    } else if (type == RT_PRIM_ABOX) {
+        *normal = abox_normal(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), ray_at(ray, best.t), flag);
+    } else {
+        // Cube::hit (src/tracer/cube.rs:110-117): the face is matched in the box's frame
+        F3 center = f3(r0.x, r0.y, r0.z), half = f3(r0.w, r1.x, r1.y);
+        Rotor rot{r1.z, r1.w, r2.x, r2.y};
+        Ray local = cube_local_ray(center, rot, ray);
+        F3 nl = abox_normal(center - half, center + half, ray_at(local, best.t), flag);
+        *normal = rotate(rot, nl);
+    }
+}
+
+// Per-lane traversal stack: the first RT_LDS_STACK entries of a lane live in LDS
+// (entry-major, so the 64 lanes of a wave hit 64 consecutive dwords), deeper ones
+// in an HBM area with the same entry-major layout over all lanes of the grid.
+struct Stack {
+    uint32_t *lds_w;  // [RT_LDS_STACK][block threads], this thread's column
+    float *lds_t;
+    uint32_t lds_stride;
+    uint2 *ovf;  // [max_stack - RT_LDS_STACK][grid threads], this thread's column
+    size_t ovf_stride;
+    int sp;
+    RT_DEV void push(uint32_t w, float t) {
+        if (sp < RT_LDS_STACK) {
+            lds_w[sp * lds_stride] = w;
+            lds_t[sp * lds_stride] = t;
+        } else {
+            ovf[(size_t)(sp - RT_LDS_STACK) * ovf_stride] = make_uint2(w, __float_as_uint(t));
+        }
+        sp++;
+    }
+    RT_DEV void pop(uint32_t *w, float *t) {
+        sp--;
+        if (sp < RT_LDS_STACK) {
+            *w = lds_w[sp * lds_stride];
+            *t = lds_t[sp * lds_stride];
+        } else {
+            uint2 e = ovf[(size_t)(sp - RT_LDS_STACK) * ovf_stride];
+            *w = e.x;
+            *t = __uint_as_float(e.y);
+        }
+    }
+};
+
+// Bvh::hit for one ray.  COUNT adds node-visit / primitive-test counters.
+template <bool COUNT>
+RT_DEV Best closest_hit(const RtSceneView &sc, const Ray &ray, float t_min, float t_max, Stack &st, uint32_t *visits,
+                        uint32_t *tests) {
+    Best best;
+    best.t = t_max;
+    best.index = -1;
+    best.u = best.v = 0.0f;
+    best.ties = false;
+    const float4 *__restrict__ nodes = (const float4 *)sc.nodes;
+    const float4 *__restrict__ prims = (const float4 *)sc.prims;
+    F3 inv = f3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    {   // the root's own box (src/tracer/bvh.rs:144-147)
+        F3 t0 = (f3(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2]) - ray.o) * inv;
+        F3 t1 = (f3(sc.root_hi[0], sc.root_hi[1], sc.root_hi[2]) - ray.o) * inv;
+        float tn = fmaxf(max3(f3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z))), t_min);
+        float tf = fminf(min3(f3(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z))), t_max);
+        if (COUNT) (*visits)++;
+        if (!(tn <= tf)) return best;
+    }
+    st.sp = 0;
+    uint32_t entry = 0;  // word of the thing to process next: node 0
+    for (;;) {
+        if (entry & RT_CHILD_LEAF) {
+            int32_t first = (int32_t)(entry & RT_LEAF_FIRST_MASK);
+            int32_t count = (int32_t)((entry >> 28) & 7u) + 1;
+            for (int32_t k = 0; k < count; k++) {
+                if (COUNT) (*tests)++;
+                test_primitive(prims, first + k, ray, t_min, t_max, best);
+            }
+        } else {
+            const float4 *n = nodes + (size_t)entry * RT_NODE_FLOAT4S;
+            float4 lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
+            float4 cwf = n[6];
+            if (COUNT) (*visits)++;
+            uint32_t cw[4] = {__float_as_uint(cwf.x), __float_as_uint(cwf.y), __float_as_uint(cwf.z), __float_as_uint(cwf.w)};
+            float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
+            float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+            float key[4];
+            const float kInf = __int_as_float(0x7f800000);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float t0x = (lx[c] - ray.o.x) * inv.x, t1x = (hx[c] - ray.o.x) * inv.x;
+                float t0y = (ly[c] - ray.o.y) * inv.y, t1y = (hy[c] - ray.o.y) * inv.y;
+                float t0z = (lz[c] - ray.o.z) * inv.z, t1z = (hz[c] - ray.o.z) * inv.z;
+                float tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), t_min);
+                float tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), best.t);
+                bool hit = (cw[c] != RT_CHILD_NONE) && (tn <= tf);
+                key[c] = hit ? tn : kInf;
+            }
+            // sort the four (key, word) pairs ascending: (0,1) (2,3) (0,2) (1,3) (1,2)
+#define RT_CSWAP(i, j)                    \
+    if (key[j] < key[i]) {                \
+        float tk = key[i];                \
+        key[i] = key[j];                  \
+        key[j] = tk;                      \
+        uint32_t tw = cw[i];              \
+        cw[i] = cw[j];                    \
+        cw[j] = tw;                       \
+    }
+            RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+            if (key[3] < kInf) st.push(cw[3], key[3]);
+            if (key[2] < kInf) st.push(cw[2], key[2]);
+            if (key[1] < kInf) st.push(cw[1], key[1]);
+            if (key[0] < kInf) {
+                entry = cw[0];
+                continue;
+            }
+        }
+        // next entry from the stack; an entry whose box starts beyond the best hit is dropped
+        bool found = false;
+        while (st.sp > 0) {
+            uint32_t w;
+            float t;
+            st.pop(&w, &t);
+            if (t <= best.t) {
+                entry = w;
+                found = true;
+                break;
+            }
+        }
+        if (!found) break;
+    }
+    return best;
+}
+
+}  // namespace rtd
+#endif

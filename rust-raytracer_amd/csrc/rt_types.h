@@ -1,0 +1,90 @@
+// rt_types.h -- data layout shared by the host-side scene builder and the HIP kernels.
+//
+// Everything the kernels read lives in HBM as arrays of 16-byte words so that a
+// lane fetches whole records with global_load_dwordx4:
+//
+//   wide node   128 B = 8 x float4   four child boxes in SoA form + four child words
+//   primitive    48 B = 3 x float4   one record per primitive, all types
+//   normals      48 B = 3 x float4   vertex normals of a triangle (same index as its record)
+//   material     32 B = 2 x float4
+//
+// Primitives are stored in the order in which the reference's recursive traversal
+// (right child first, src/tracer/bvh.rs:148-155) reaches its leaves, so the array
+// index of a primitive is its "visit rank"; equal-distance hits are resolved with
+// it (see rt_traverse.hpp).
+#ifndef RT_TYPES_H
+#define RT_TYPES_H
+
+#include <stdint.h>
+
+// ---- wide node -----------------------------------------------------------
+// float4 0..5 : lo.x[4], lo.y[4], lo.z[4], hi.x[4], hi.y[4], hi.z[4]   (one lane of the float4 per child)
+// float4 6    : child words (as raw bits)
+// float4 7    : unused
+//
+// child word: RT_CHILD_NONE            empty slot
+//             bit 31 clear             index of another wide node
+//             bit 31 set               leaf: bits 28..30 = primitive count - 1, bits 0..27 = first primitive
+#define RT_NODE_FLOAT4S 8
+#define RT_CHILD_NONE 0xFFFFFFFFu
+#define RT_CHILD_LEAF 0x80000000u
+#define RT_LEAF_MAX_PRIMS 7u
+#define RT_LEAF_FIRST_MASK 0x0FFFFFFFu
+
+// ---- primitive record ------------------------------------------------------
+// word 10 = meta, word 11 = primitive id (scene declaration order)
+// meta: bits 0..2 type, bit 3 flag (triangle: two_sided, boxes: hollow), bits 4..31 material index
+//   triangle : w0..2 v0, w3..5 e1 = v1 - v0, w6..8 e2 = v2 - v0
+//   sphere   : w0..2 center, w3 radius
+//   abox     : w0..2 min, w3..5 max
+//   cube     : w0..2 center, w3..5 half extents, w6..9 rotor (s, xy, xz, yz)
+#define RT_PRIM_FLOAT4S 3
+#define RT_PRIM_TRIANGLE 0u
+#define RT_PRIM_SPHERE 1u
+#define RT_PRIM_ABOX 2u
+#define RT_PRIM_CUBE 3u
+#define RT_PRIM_TYPE_MASK 7u
+#define RT_PRIM_FLAG 8u
+#define RT_PRIM_MAT_SHIFT 4
+
+// LDS entries of the per-lane traversal stack; deeper entries go to an HBM overflow area.
+#define RT_LDS_STACK 16
+
+struct RtDevMaterial {  // 32 B
+    float albedo[3];
+    int32_t type;
+    float p0, p1;
+    float pad[2];
+};
+
+struct RtDevCamera {
+    float eye[3];
+    float lens_radius;
+    float horizontal[3];
+    float pad0;
+    float vertical[3];
+    float pad1;
+    float llc[3];
+    float pad2;
+    float u[3];
+    float pad3;
+    float v[3];
+    float pad4;
+};
+
+// What a kernel needs to see of a scene (passed by value).
+struct RtSceneView {
+    const void *nodes;       // float4[n_nodes * 8]
+    const void *prims;       // float4[n_prims * 3]
+    const void *tri_normals; // float4[n_prims * 3]
+    const void *materials;   // RtDevMaterial[n_materials]
+    const float *env;        // rgb float triples or nullptr
+    uint32_t env_w, env_h;
+    uint32_t n_nodes, n_prims;
+    float root_lo[3];
+    float root_hi[3];
+    uint32_t max_stack; // upper bound of traversal stack entries for this tree
+    uint32_t pad;
+};
+
+#endif

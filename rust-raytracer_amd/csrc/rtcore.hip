@@ -1,0 +1,784 @@
+// rtcore.hip -- kernels of the wavefront path tracer and the C ABI (include/rtcore.h).
+//
+// Stages of one batch of paths (all state is structure-of-arrays float4 in HBM):
+//
+//   generate    one lane per path: camera ray (Camera::gen_ray), throughput 1, RNG key
+//   extend      one lane per live path: closest hit through the 4-wide tree
+//   shade       one lane per live path: scatter / Russian roulette / emitter / sky;
+//               finished paths store their radiance sample, survivors are compacted
+//               into the other state buffer (wave ballot + prefix popcount, one
+//               atomic per wave)
+//   accumulate  one lane per pixel: sums that pixel's samples in sample order with
+//               the reference's non-finite scrub and adds the mean to the frame
+//
+// A batch holds all `samples` paths of a run of consecutive pixels, sample-major
+// (slot = sample * pixels + pixel), so the accumulate stage reads coalesced and
+// every radiance sample is written exactly once -- no float atomics anywhere.
+// Live-path counts stay on the device; kernels read them and idle lanes exit, so
+// a pass needs no host synchronisation.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/rtcore.h"
+#include "rt_device.hpp"
+#include "rt_traverse.hpp"
+#include "scene_build.hpp"
+
+using namespace rtd;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr float kTMin = 0.00015f;   // src/render.rs:15
+constexpr float kTMax = 100000.0f;  // src/render.rs:16
+
+struct PathState {
+    float4 *o;    // origin, .w = radiance slot (bits)
+    float4 *d;    // direction (normalised), .w unused
+    float4 *thr;  // throughput, .w = RNG key (bits)
+};
+
+// ---------------------------------------------------------------------------
+// generate: Renderer::render's per-sample setup (src/render.rs:176-201)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint32_t width, uint32_t height,
+                                                           uint32_t spp, uint32_t pass, uint32_t seed, uint32_t p0,
+                                                           uint32_t np, uint32_t preview, PathState out,
+                                                           uint32_t *counts, uint32_t n_counts) {
+    uint32_t n = np * spp;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        counts[0] = n;
+        for (uint32_t k = 1; k < n_counts; k++) counts[k] = 0;
+    }
+    if (i >= n) return;
+    uint32_t s = i / np, j = i - s * np;
+    uint32_t pixel = p0 + j;
+    float x = (float)(pixel % width);
+    float y = (float)(height - 1 - pixel / width);
+    float jx, jy;
+    pixel_jitter(seed, pixel, pass, s, &jx, &jy);
+    uint32_t key = path_key(seed, pixel, preview ? pass : pass * spp + s);
+    F3 org, dir;
+    gen_ray(cam, width, height, x, y, jx, jy, &org, &dir);
+    dir = normalized(dir);  // Ray::new (src/ray.rs:10-15)
+    out.o[i] = make_float4(org.x, org.y, org.z, __uint_as_float(i));
+    out.d[i] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+    out.thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(key));
+}
+
+// ---------------------------------------------------------------------------
+// extend: Bvh::hit for every live path (src/tracer/bvh.rs:143)
+// hit_a = (t, visit rank, material, primitive id)   rank -1 = miss
+// hit_n = (normal, 0)
+// ---------------------------------------------------------------------------
+template <bool COUNT>
+__global__ void __launch_bounds__(kBlock)
+    extend_kernel(RtSceneView sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
+                  const uint32_t *__restrict__ count_ptr, uint32_t n_fixed, float t_min, float t_max,
+                  float4 *__restrict__ hit_a, float4 *__restrict__ hit_n, uint2 *ovf,
+                  unsigned long long *counters) {
+    __shared__ uint32_t s_w[RT_LDS_STACK * kBlock];
+    __shared__ float s_t[RT_LDS_STACK * kBlock];
+    const uint32_t n = count_ptr ? *count_ptr : n_fixed;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    Stack st;
+    st.lds_w = s_w + threadIdx.x;
+    st.lds_t = s_t + threadIdx.x;
+    st.lds_stride = kBlock;
+    st.ovf = ovf + gtid;
+    st.ovf_stride = stride;
+    st.sp = 0;
+    uint32_t visits = 0, tests = 0;
+    for (uint32_t i = gtid; i < n; i += stride) {
+        float4 o4 = ro[i], d4 = rd[i];
+        Ray ray;
+        ray.o = f3(o4.x, o4.y, o4.z);
+        ray.d = f3(d4.x, d4.y, d4.z);
+        Best best = closest_hit<COUNT>(sc, ray, t_min, t_max, st, &visits, &tests);
+        if (best.index >= 0) {
+            F3 nrm;
+            uint32_t mat;
+            int32_t pid;
+            finish_hit(sc, ray, best, &nrm, &mat, &pid);
+            hit_a[i] = make_float4(best.t, __int_as_float(best.index), __uint_as_float(mat), __int_as_float(pid));
+            hit_n[i] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+        } else {
+            hit_a[i] = make_float4(0.0f, __int_as_float(-1), 0.0f, __int_as_float(-1));
+            hit_n[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    }
+    if (COUNT) {
+        atomicAdd(&counters[0], (unsigned long long)visits);
+        atomicAdd(&counters[1], (unsigned long long)tests);
+    }
+}
+
+// Appends the lanes with `alive` to a queue: one atomic per wave, slot = base + rank among the wave's live lanes.
+__device__ __forceinline__ uint32_t wave_compact_slot(bool alive, uint32_t *counter) {
+    unsigned long long mask = __ballot(alive);
+    uint32_t lane = __lane_id();
+    uint32_t total = (uint32_t)__popcll(mask);
+    uint32_t base = 0;
+    if (total) {
+        uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+        if (lane == leader) base = atomicAdd(counter, total);
+        base = (uint32_t)__shfl((int)base, (int)leader);
+    }
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// ---------------------------------------------------------------------------
+// shade: the body of ray_color's loop (src/render.rs:62-81) for bounce `bounce`
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    shade_kernel(RtSceneView sc, PathState in, const float4 *__restrict__ hit_a, const float4 *__restrict__ hit_n,
+                 const uint32_t *__restrict__ count_in, PathState out, uint32_t *count_out, float4 *__restrict__ rad,
+                 uint32_t bounce, uint32_t depth, float light_clamp) {
+    const uint32_t n = *count_in;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const RtDevMaterial *mats = (const RtDevMaterial *)sc.materials;
+    // every lane of a wave runs the same number of iterations so the ballot sees whole waves
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        bool alive = false;
+        float4 o4, d4, th4;
+        F3 new_o, new_d, thr;
+        if (i < n) {
+            o4 = in.o[i];
+            d4 = in.d[i];
+            th4 = in.thr[i];
+            float4 ha = hit_a[i];
+            uint32_t slot = __float_as_uint(o4.w);
+            uint32_t key = __float_as_uint(th4.w);
+            Ray ray;
+            ray.o = f3(o4.x, o4.y, o4.z);
+            ray.d = f3(d4.x, d4.y, d4.z);
+            thr = f3(th4.x, th4.y, th4.z);
+            F3 result;
+            if (__float_as_int(ha.y) >= 0) {
+                float4 hn = hit_n[i];
+                RtDevMaterial m = mats[__float_as_uint(ha.z)];
+                F3 sdir;
+                F3 att = scatter(m, ray, ha.x, f3(hn.x, hn.y, hn.z), key, bounce, &sdir);
+                if (max3(att) <= 1.0f) {
+                    thr = thr * att;
+                    if (max3(thr) < draw(key, bounce, DIM_RR)) {
+                        result = thr * 0.01f;  // Russian-roulette break, src/render.rs:68-70,83
+                    } else {
+                        thr = thr * (1.0f / max3(thr));
+                        if (bounce + 1 == depth) {
+                            result = thr * 0.01f;  // depth exhausted, src/render.rs:83
+                        } else {
+                            alive = true;
+                            new_o = ray_at(ray, ha.x);
+                            new_d = normalized(sdir);
+                        }
+                    }
+                } else {
+                    result = thr * clamped(att, 0.0f, 1.0f * light_clamp);  // emitter, src/render.rs:73-77
+                }
+            } else {
+                result = thr * get_sky(sc, ray.d, light_clamp);  // src/render.rs:80
+            }
+            if (!alive) rad[slot] = make_float4(result.x, result.y, result.z, 0.0f);
+        }
+        uint32_t dst = wave_compact_slot(alive, count_out);
+        if (alive) {
+            out.o[dst] = make_float4(new_o.x, new_o.y, new_o.z, o4.w);
+            out.d[dst] = make_float4(new_d.x, new_d.y, new_d.z, 0.0f);
+            out.thr[dst] = make_float4(thr.x, thr.y, thr.z, th4.w);
+        }
+    }
+}
+
+// normals_only / colors_only / no_bounce (src/render.rs:107-138): every path ends after its first hit
+__global__ void __launch_bounds__(kBlock)
+    shade_first_hit_kernel(RtSceneView sc, PathState in, const float4 *__restrict__ hit_a,
+                           const float4 *__restrict__ hit_n, const uint32_t *__restrict__ count_in,
+                           float4 *__restrict__ rad, int mode) {
+    const uint32_t n = *count_in;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const RtDevMaterial *mats = (const RtDevMaterial *)sc.materials;
+    const float kInf = __int_as_float(0x7f800000);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float4 o4 = in.o[i], d4 = in.d[i], th4 = in.thr[i], ha = hit_a[i];
+        uint32_t slot = __float_as_uint(o4.w);
+        Ray ray;
+        ray.o = f3(o4.x, o4.y, o4.z);
+        ray.d = f3(d4.x, d4.y, d4.z);
+        F3 result;
+        if (__float_as_int(ha.y) >= 0) {
+            float4 hn = hit_n[i];
+            F3 nrm = f3(hn.x, hn.y, hn.z);
+            RtDevMaterial m = mats[__float_as_uint(ha.z)];
+            if (mode == RT_MODE_NORMALS) {
+                result = (nrm + f3(1.0f, 1.0f, 1.0f)) * 0.5f;
+            } else if (mode == RT_MODE_COLORS) {
+                result = f3(m.albedo[0], m.albedo[1], m.albedo[2]);
+            } else {
+                F3 sdir;
+                F3 att = scatter(m, ray, ha.x, nrm, __float_as_uint(th4.w), 0, &sdir);
+                float k = rclamp(dot(normalized(f3(1.0f, 1.0f, -0.5f)), nrm), 0.1f, 1.0f);
+                result = k * att;
+            }
+        } else {
+            result = get_sky(sc, ray.d, kInf);
+        }
+        rad[slot] = make_float4(result.x, result.y, result.z, 0.0f);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) fill_radiance_kernel(float4 *rad, uint32_t n, float v) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rad[i] = make_float4(v, v, v, 0.0f);
+}
+
+// ---------------------------------------------------------------------------
+// accumulate: the tail of Renderer::render's per-pixel closure (src/render.rs:203-214)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    accumulate_kernel(const float4 *__restrict__ rad, uint32_t np, uint32_t spp, uint32_t p0, float *accum,
+                      int overwrite) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= np) return;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    const float kInf = __int_as_float(0x7f800000);
+    for (uint32_t s = 0; s < spp; s++) {
+        float4 c = rad[(size_t)s * np + j];
+        sx += c.x;
+        sy += c.y;
+        sz += c.z;
+        if (!(fabsf(sx) < kInf)) sx = 0.0f;
+        if (!(fabsf(sy) < kInf)) sy = 0.0f;
+        if (!(fabsf(sz) < kInf)) sz = 0.0f;
+    }
+    size_t p = (size_t)(p0 + j) * 3;
+    if (overwrite) {
+        // Renderer::preview returns the sample itself (src/render.rs:243-259)
+        float4 c = rad[j];
+        accum[p] = c.x, accum[p + 1] = c.y, accum[p + 2] = c.z;
+    } else {
+        float f = (float)spp;
+        accum[p] = accum[p] + sx / f;
+        accum[p + 1] = accum[p + 1] + sy / f;
+        accum[p + 2] = accum[p + 2] + sz / f;
+    }
+}
+
+__global__ void tally_kernel(const uint32_t *counts, uint32_t n_bounces, unsigned long long *totals) {
+    unsigned long long rays = 0;
+    for (uint32_t b = 0; b < n_bounces; b++) rays += counts[b];
+    totals[0] += rays;
+    totals[1] += counts[0];
+}
+
+// ---------------------------------------------------------------------------
+// closest-hit batch I/O
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+    pack_rays_kernel(const float *__restrict__ org_dir, uint32_t n, float4 *ro, float4 *rd) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *r = org_dir + (size_t)i * 6;
+    F3 d = normalized(f3(r[3], r[4], r[5]));  // Ray::new
+    ro[i] = make_float4(r[0], r[1], r[2], 0.0f);
+    rd[i] = make_float4(d.x, d.y, d.z, 0.0f);
+}
+__global__ void __launch_bounds__(kBlock)
+    unpack_hits_kernel(const float4 *__restrict__ hit_a, const float4 *__restrict__ hit_n,
+                       const float4 *__restrict__ ro, const float4 *__restrict__ rd, uint32_t n, int32_t *prim_id,
+                       float *t, float *normal, float *point) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 ha = hit_a[i], hn = hit_n[i];
+    bool ok = __float_as_int(ha.y) >= 0;
+    if (prim_id) prim_id[i] = __float_as_int(ha.w);
+    if (t) t[i] = ok ? ha.x : 0.0f;
+    if (normal) {
+        normal[(size_t)i * 3] = hn.x, normal[(size_t)i * 3 + 1] = hn.y, normal[(size_t)i * 3 + 2] = hn.z;
+    }
+    if (point) {
+        float4 o4 = ro[i], d4 = rd[i];
+        Ray ray;
+        ray.o = f3(o4.x, o4.y, o4.z);
+        ray.d = f3(d4.x, d4.y, d4.z);
+        F3 p = ok ? ray_at(ray, ha.x) : f3(0.0f, 0.0f, 0.0f);
+        point[(size_t)i * 3] = p.x, point[(size_t)i * 3 + 1] = p.y, point[(size_t)i * 3 + 2] = p.z;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg) {
+    g_error = msg;
+    return code;
+}
+#define RT_HIP(call)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fail(RT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t want) {
+        if (want <= bytes) return RT_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            p = nullptr;
+            return fail(RT_ERR_OUT_OF_MEMORY, "hipMalloc of " + std::to_string(want) + " bytes failed");
+        }
+        bytes = want;
+        return RT_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct TimedSpan {
+    hipEvent_t a, b;
+    int stage;  // 0 extend, 1 shade, 2 other
+};
+
+}  // namespace
+
+struct RtScene {
+    int device = 0;
+    int n_cus = 256;
+    rtcore::HostScene host;  // metadata only after upload (big arrays are released)
+    DevBuf nodes, prims, normals, materials, env;
+    RtSceneView view{};
+    // work buffers
+    DevBuf st_o[2], st_d[2], st_thr[2], hit_a, hit_n, rad, counts, totals, ovf, counters, accum_tmp, io_a, io_b, io_c,
+        io_d, io_e;
+    uint64_t work_paths = 0;
+    uint32_t extend_blocks = 0;
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> event_pool;
+    size_t events_used = 0;
+    RtStats stats{};
+    uint64_t device_bytes = 0;
+};
+
+namespace {
+
+int ensure_work(RtScene *s, uint64_t paths) {
+    if (paths <= s->work_paths && s->extend_blocks) return RT_OK;
+    int rc;
+    for (int k = 0; k < 2; k++) {
+        if ((rc = s->st_o[k].ensure(paths * 16))) return rc;
+        if ((rc = s->st_d[k].ensure(paths * 16))) return rc;
+        if ((rc = s->st_thr[k].ensure(paths * 16))) return rc;
+    }
+    if ((rc = s->hit_a.ensure(paths * 16))) return rc;
+    if ((rc = s->hit_n.ensure(paths * 16))) return rc;
+    if ((rc = s->rad.ensure(paths * 16))) return rc;
+    if ((rc = s->counts.ensure(4096))) return rc;
+    if (!s->totals.p) {
+        if ((rc = s->totals.ensure(64))) return rc;
+        RT_HIP(hipMemset(s->totals.p, 0, 64));
+    }
+    if (!s->counters.p) {
+        if ((rc = s->counters.ensure(64))) return rc;
+        RT_HIP(hipMemset(s->counters.p, 0, 64));
+    }
+    s->extend_blocks = (uint32_t)s->n_cus * 8u;
+    uint32_t deep = s->view.max_stack > RT_LDS_STACK ? s->view.max_stack - RT_LDS_STACK : 0;
+    if (deep) {
+        if ((rc = s->ovf.ensure((size_t)deep * s->extend_blocks * kBlock * sizeof(uint2)))) return rc;
+    }
+    s->work_paths = paths;
+    return RT_OK;
+}
+
+hipEvent_t take_event(RtScene *s) {
+    if (s->events_used == s->event_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        s->event_pool.push_back(e);
+    }
+    return s->event_pool[s->events_used++];
+}
+struct StageTimer {
+    RtScene *s;
+    hipStream_t stream;
+    hipEvent_t a = nullptr;
+    int stage;
+    StageTimer(RtScene *sc, hipStream_t st, int stg) : s(sc), stream(st), stage(stg) {
+        if (s->timing) {
+            a = take_event(s);
+            if (a) (void)hipEventRecord(a, stream);
+        }
+    }
+    ~StageTimer() {
+        if (s->timing && a) {
+            hipEvent_t b = take_event(s);
+            if (b) {
+                (void)hipEventRecord(b, stream);
+                s->spans.push_back(TimedSpan{a, b, stage});
+            }
+        }
+    }
+};
+
+uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
+
+int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4 *rd, const uint32_t *count_ptr,
+                  uint32_t n_upper, float t_min, float t_max, bool counted) {
+    if (n_upper == 0) return RT_OK;
+    uint32_t blocks = std::min(blocks_for(n_upper), s->extend_blocks);
+    StageTimer tm(s, stream, 0);
+    if (counted)
+        hipLaunchKernelGGL(extend_kernel<true>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
+                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (float4 *)s->hit_n.p, (uint2 *)s->ovf.p,
+                           (unsigned long long *)s->counters.p);
+    else
+        hipLaunchKernelGGL(extend_kernel<false>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
+                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (float4 *)s->hit_n.p, (uint2 *)s->ovf.p,
+                           (unsigned long long *)s->counters.p);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
+}
+
+int check_params(const RtScene *s, const RtRenderParams *p, const void *buf) {
+    if (!s || !p || !buf) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (p->width < 2 || p->height < 2) return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be at least 2");
+    if ((uint64_t)p->width * p->height > 0x7fffffffull) return fail(RT_ERR_INVALID_ARGUMENT, "frame too large");
+    if (p->samples == 0) return fail(RT_ERR_INVALID_ARGUMENT, "samples must be positive");
+    if (p->max_bounce > 1000) return fail(RT_ERR_INVALID_ARGUMENT, "max_bounce too large");
+    if (p->mode < RT_MODE_NORMALS || p->mode > RT_MODE_IMAGE) return fail(RT_ERR_INVALID_ARGUMENT, "unknown mode");
+    return RT_OK;
+}
+
+// One pass (or one preview frame) on device memory.
+int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream_t stream, bool preview) {
+    int rc = check_params(s, p, d_accum);
+    if (rc) return rc;
+    RT_HIP(hipSetDevice(s->device));
+    const uint32_t spp = preview ? 1u : p->samples;
+    const uint64_t pixels = (uint64_t)p->width * p->height;
+    uint64_t budget = p->batch_paths ? p->batch_paths : (1ull << 23);
+    if (budget > (1ull << 30)) budget = 1ull << 30;
+    uint64_t np_max = budget / spp;
+    if (np_max == 0) np_max = 1;
+    if (np_max > pixels) np_max = pixels;
+    if (np_max * spp > 0x7fffffffull) return fail(RT_ERR_INVALID_ARGUMENT, "samples too large for one batch");
+    if ((rc = ensure_work(s, np_max * spp))) return rc;
+
+    RtDevCamera cam;
+    rtcore::make_camera(s->host.camera, (float)p->width / (float)p->height, cam);
+    const bool first_hit_only = preview || p->mode != RT_MODE_IMAGE;
+    const uint32_t depth = first_hit_only ? 1u : p->max_bounce;
+    const uint32_t n_counts = depth + 2;
+    if (n_counts > 1024) return fail(RT_ERR_INVALID_ARGUMENT, "max_bounce too large");
+    uint32_t *counts = (uint32_t *)s->counts.p;
+    PathState st[2];
+    for (int k = 0; k < 2; k++) st[k] = PathState{(float4 *)s->st_o[k].p, (float4 *)s->st_d[k].p, (float4 *)s->st_thr[k].p};
+    float4 *rad = (float4 *)s->rad.p;
+
+    for (uint64_t p0 = 0; p0 < pixels; p0 += np_max) {
+        const uint32_t np = (uint32_t)std::min<uint64_t>(np_max, pixels - p0);
+        const uint32_t n = np * spp;
+        {
+            StageTimer tm(s, stream, 2);
+            hipLaunchKernelGGL(generate_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, cam, p->width,
+                               p->height, spp, p->pass_index, p->seed, (uint32_t)p0, np, preview ? 1u : 0u, st[0],
+                               counts, n_counts);
+        }
+        if (depth == 0) {
+            // ray_color's loop body never runs: every sample is 1 * 0.01 (src/render.rs:61,83)
+            hipLaunchKernelGGL(fill_radiance_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, rad, n, 0.01f);
+        }
+        int cur = 0;
+        for (uint32_t b = 0; b < depth; b++) {
+            if ((rc = launch_extend(s, stream, st[cur].o, st[cur].d, counts + b, n, kTMin, kTMax, false))) return rc;
+            StageTimer tm(s, stream, 1);
+            uint32_t blocks = std::min(blocks_for(n), (uint32_t)s->n_cus * 16u);
+            if (first_hit_only) {
+                hipLaunchKernelGGL(shade_first_hit_kernel, dim3(blocks), dim3(kBlock), 0, stream, s->view, st[cur],
+                                   (const float4 *)s->hit_a.p, (const float4 *)s->hit_n.p, counts + b, rad,
+                                   preview && p->mode == RT_MODE_IMAGE ? (int)RT_MODE_IMAGE : (int)p->mode);
+            } else {
+                hipLaunchKernelGGL(shade_kernel, dim3(blocks), dim3(kBlock), 0, stream, s->view, st[cur],
+                                   (const float4 *)s->hit_a.p, (const float4 *)s->hit_n.p, counts + b, st[cur ^ 1],
+                                   counts + b + 1, rad, b, depth, p->light_clamp);
+            }
+            cur ^= 1;
+        }
+        {
+            StageTimer tm(s, stream, 2);
+            hipLaunchKernelGGL(accumulate_kernel, dim3(blocks_for(np)), dim3(kBlock), 0, stream, rad, np, spp,
+                               (uint32_t)p0, d_accum, preview ? 1 : 0);
+            hipLaunchKernelGGL(tally_kernel, dim3(1), dim3(1), 0, stream, counts, depth, (unsigned long long *)s->totals.p);
+        }
+        RT_HIP(hipGetLastError());
+    }
+    return RT_OK;
+}
+
+void collect_timing(RtScene *s) {
+    for (auto &sp : s->spans) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) {
+            if (sp.stage == 0)
+                s->stats.extend_ms += ms;
+            else if (sp.stage == 1)
+                s->stats.shade_ms += ms;
+            else
+                s->stats.other_ms += ms;
+        }
+    }
+    s->spans.clear();
+    s->events_used = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rt_last_error(void) { return g_error.c_str(); }
+const char *rt_version(void) { return "rtcore-mi355x 0.1 (gfx950)"; }
+
+int rt_init(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0) return fail(RT_ERR_DEVICE, "no HIP device is visible");
+    if (device >= 0) {
+        if (device >= n) return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
+        RT_HIP(hipSetDevice(device));
+    }
+    return RT_OK;
+}
+
+int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
+    if (!desc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return fail(RT_ERR_DEVICE, "no HIP device is visible; the core has no CPU path");
+    std::unique_ptr<RtScene> s(new RtScene());
+    std::string err;
+    int rc = rtcore::build_host_scene(desc, s->host, err);
+    if (rc) return fail(rc, err);
+    RT_HIP(hipGetDevice(&s->device));
+    hipDeviceProp_t prop;
+    RT_HIP(hipGetDeviceProperties(&prop, s->device));
+    s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+
+    rtcore::HostScene &h = s->host;
+    auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
+        if (bytes == 0) return RT_OK;
+        int r = b.ensure(bytes);
+        if (r) return r;
+        RT_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+        s->device_bytes += bytes;
+        return RT_OK;
+    };
+    if ((rc = upload(s->nodes, h.nodes.data(), h.nodes.size() * 4))) return rc;
+    if ((rc = upload(s->prims, h.prims.data(), h.prims.size() * 4))) return rc;
+    if ((rc = upload(s->normals, h.tri_normals.data(), h.tri_normals.size() * 4))) return rc;
+    if ((rc = upload(s->materials, h.materials.data(), h.materials.size() * sizeof(RtDevMaterial)))) return rc;
+    if ((rc = upload(s->env, h.env.data(), h.env.size() * 4))) return rc;
+    RtSceneView &v = s->view;
+    v.nodes = s->nodes.p;
+    v.prims = s->prims.p;
+    v.tri_normals = s->normals.p;
+    v.materials = s->materials.p;
+    v.env = (const float *)s->env.p;
+    v.env_w = h.env_w;
+    v.env_h = h.env_h;
+    v.n_nodes = (uint32_t)h.n_nodes;
+    v.n_prims = (uint32_t)h.n_prims;
+    for (int k = 0; k < 3; k++) v.root_lo[k] = h.root_lo[k], v.root_hi[k] = h.root_hi[k];
+    v.max_stack = h.max_stack;
+    // the device copies are what the kernels read; drop the host arrays
+    std::vector<float>().swap(h.nodes);
+    std::vector<uint32_t>().swap(h.prims);
+    std::vector<float>().swap(h.tri_normals);
+    std::vector<float>().swap(h.env);
+    *out = s.release();
+    return RT_OK;
+}
+
+int rt_scene_destroy(RtScene *s) {
+    if (!s) return RT_OK;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    DevBuf *all[] = {&s->nodes, &s->prims, &s->normals, &s->materials, &s->env, &s->st_o[0], &s->st_o[1], &s->st_d[0],
+                     &s->st_d[1], &s->st_thr[0], &s->st_thr[1], &s->hit_a, &s->hit_n, &s->rad, &s->counts, &s->totals,
+                     &s->ovf, &s->counters, &s->accum_tmp, &s->io_a, &s->io_b, &s->io_c, &s->io_d, &s->io_e};
+    for (DevBuf *b : all) b->release();
+    for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
+    delete s;
+    return RT_OK;
+}
+
+int rt_scene_info(const RtScene *s, RtSceneInfo *info) {
+    if (!s || !info) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    std::memset(info, 0, sizeof(*info));
+    info->n_primitives = s->host.n_prims;
+    info->n_triangles = s->host.n_triangles;
+    info->n_wide_nodes = s->host.n_nodes;
+    info->n_binary_nodes = s->host.n_binary_nodes;
+    info->wide_depth = s->host.wide_depth;
+    info->node_bytes = RT_NODE_FLOAT4S * 16;
+    info->primitive_bytes = RT_PRIM_FLOAT4S * 16;
+    info->device_bytes = s->device_bytes;
+    for (int k = 0; k < 3; k++) info->bounds_min[k] = s->host.root_lo[k], info->bounds_max[k] = s->host.root_hi[k];
+    return RT_OK;
+}
+
+int rt_set_stage_timing(RtScene *s, int enabled) {
+    if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    s->timing = enabled != 0;
+    return RT_OK;
+}
+
+// Reads the device-side counters (synchronises the device) and resets them.
+int rt_scene_stats(const RtScene *cs, RtStats *out) {
+    RtScene *s = const_cast<RtScene *>(cs);
+    if (!s || !out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    RT_HIP(hipSetDevice(s->device));
+    RT_HIP(hipDeviceSynchronize());
+    collect_timing(s);
+    if (s->totals.p) {
+        unsigned long long t[2] = {0, 0};
+        RT_HIP(hipMemcpy(t, s->totals.p, sizeof(t), hipMemcpyDeviceToHost));
+        s->stats.rays += t[0];
+        s->stats.paths += t[1];
+        RT_HIP(hipMemset(s->totals.p, 0, 64));
+    }
+    if (s->counters.p) {
+        unsigned long long c[2] = {0, 0};
+        RT_HIP(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
+        s->stats.node_visits += c[0];
+        s->stats.prim_tests += c[1];
+        RT_HIP(hipMemset(s->counters.p, 0, 64));
+    }
+    *out = s->stats;
+    s->stats = RtStats{};
+    return RT_OK;
+}
+
+int rt_render_pass_device(RtScene *s, const RtRenderParams *p, float *d_accum, void *stream) {
+    return render_device(s, p, d_accum, (hipStream_t)stream, false);
+}
+int rt_preview_device(RtScene *s, const RtRenderParams *p, float *d_out, void *stream) {
+    return render_device(s, p, d_out, (hipStream_t)stream, true);
+}
+
+static int render_host(RtScene *s, const RtRenderParams *p, float *buf, bool preview) {
+    int rc = check_params(s, p, buf);
+    if (rc) return rc;
+    RT_HIP(hipSetDevice(s->device));
+    size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
+    if ((rc = s->accum_tmp.ensure(bytes))) return rc;
+    if (!preview) RT_HIP(hipMemcpy(s->accum_tmp.p, buf, bytes, hipMemcpyHostToDevice));
+    if ((rc = render_device(s, p, (float *)s->accum_tmp.p, nullptr, preview))) return rc;
+    RT_HIP(hipMemcpy(buf, s->accum_tmp.p, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+int rt_render_pass(RtScene *s, const RtRenderParams *p, float *accum) { return render_host(s, p, accum, false); }
+int rt_preview(RtScene *s, const RtRenderParams *p, float *out) { return render_host(s, p, out, true); }
+
+static int closest_hit_device(RtScene *s, const float *d_org_dir, float t_min, float t_max, size_t n, int32_t *d_id,
+                              float *d_t, float *d_normal, float *d_point, hipStream_t stream, bool counted) {
+    if (!s || (n && !d_org_dir)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(s->device));
+    const size_t chunk_max = 1u << 24;
+    int rc = ensure_work(s, std::min(n, chunk_max));
+    if (rc) return rc;
+    for (size_t off = 0; off < n; off += chunk_max) {
+        uint32_t m = (uint32_t)std::min(chunk_max, n - off);
+        float4 *ro = (float4 *)s->st_o[0].p, *rd = (float4 *)s->st_d[0].p;
+        {
+            StageTimer tm(s, stream, 2);
+            hipLaunchKernelGGL(pack_rays_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream, d_org_dir + off * 6, m, ro, rd);
+        }
+        if ((rc = launch_extend(s, stream, ro, rd, nullptr, m, t_min, t_max, counted))) return rc;
+        {
+            StageTimer tm(s, stream, 2);
+            hipLaunchKernelGGL(unpack_hits_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream,
+                               (const float4 *)s->hit_a.p, (const float4 *)s->hit_n.p, ro, rd, m,
+                               d_id ? d_id + off : nullptr, d_t ? d_t + off : nullptr,
+                               d_normal ? d_normal + off * 3 : nullptr, d_point ? d_point + off * 3 : nullptr);
+        }
+        RT_HIP(hipGetLastError());
+    }
+    s->stats.rays += n;
+    return RT_OK;
+}
+
+int rt_closest_hit_batch_device(RtScene *s, const float *d_org_dir, float t_min, float t_max, size_t n, int32_t *d_id,
+                                float *d_t, float *d_normal, float *d_point, void *stream) {
+    return closest_hit_device(s, d_org_dir, t_min, t_max, n, d_id, d_t, d_normal, d_point, (hipStream_t)stream, false);
+}
+int rt_closest_hit_batch_counted_device(RtScene *s, const float *d_org_dir, float t_min, float t_max, size_t n,
+                                        int32_t *d_id, float *d_t, float *d_normal, float *d_point, void *stream) {
+    return closest_hit_device(s, d_org_dir, t_min, t_max, n, d_id, d_t, d_normal, d_point, (hipStream_t)stream, true);
+}
+
+int rt_closest_hit_batch(RtScene *s, const float *org_dir, float t_min, float t_max, size_t n, int32_t *prim_id, float *t,
+                         float *normal, float *point) {
+    if (!s || (n && !org_dir)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n == 0) return RT_OK;
+    RT_HIP(hipSetDevice(s->device));
+    int rc;
+    if ((rc = s->io_a.ensure(n * 24))) return rc;
+    if ((rc = s->io_b.ensure(n * 4))) return rc;
+    if ((rc = s->io_c.ensure(n * 4))) return rc;
+    if ((rc = s->io_d.ensure(n * 12))) return rc;
+    if ((rc = s->io_e.ensure(n * 12))) return rc;
+    RT_HIP(hipMemcpy(s->io_a.p, org_dir, n * 24, hipMemcpyHostToDevice));
+    if ((rc = closest_hit_device(s, (const float *)s->io_a.p, t_min, t_max, n, (int32_t *)s->io_b.p, (float *)s->io_c.p,
+                                 (float *)s->io_d.p, (float *)s->io_e.p, nullptr, false)))
+        return rc;
+    RT_HIP(hipDeviceSynchronize());
+    if (prim_id) RT_HIP(hipMemcpy(prim_id, s->io_b.p, n * 4, hipMemcpyDeviceToHost));
+    if (t) RT_HIP(hipMemcpy(t, s->io_c.p, n * 4, hipMemcpyDeviceToHost));
+    if (normal) RT_HIP(hipMemcpy(normal, s->io_d.p, n * 12, hipMemcpyDeviceToHost));
+    if (point) RT_HIP(hipMemcpy(point, s->io_e.p, n * 12, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// to_rgb / aces_tonemap (src/render.rs:19-55); host arithmetic only
+uint32_t rt_to_rgb(const float rgb[3], float inv_gamma) {
+    const float m1[3][3] = {{0.59719f, 0.07600f, 0.02840f}, {0.35458f, 0.90834f, 0.13383f}, {0.04823f, 0.01566f, 0.83777f}};
+    const float m2[3][3] = {{1.60475f, -0.10208f, -0.00327f}, {-0.53108f, 1.10813f, -0.07276f}, {-0.07367f, -0.00605f, 1.07602f}};
+    float v[3], q[3], o[3];
+    for (int k = 0; k < 3; k++) v[k] = m1[0][k] * rgb[0] + m1[1][k] * rgb[1] + m1[2][k] * rgb[2];
+    for (int k = 0; k < 3; k++) {
+        float a = v[k] * (v[k] + 0.0245786f) - 0.000090537f;
+        float b = v[k] * (0.983729f * v[k] + 0.432951f) + 0.238081f;
+        q[k] = a / b;
+    }
+    uint32_t out = 255u << 24;
+    for (int k = 0; k < 3; k++) {
+        o[k] = m2[0][k] * q[0] + m2[1][k] * q[1] + m2[2][k] * q[2];
+        o[k] = std::fmin(std::fmax(o[k], 0.0f), 1.0f);
+        o[k] = std::pow(o[k], inv_gamma);
+        out |= ((uint32_t)(o[k] * 255.4f)) << (16 - 8 * k);
+    }
+    return out;
+}
+
+}  // extern "C"

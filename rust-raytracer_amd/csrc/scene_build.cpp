@@ -1,0 +1,637 @@
+// scene_build.cpp -- host side of rt_scene_create.
+//
+// 1. expand the scene objects into primitives (ids in declaration order) with their
+//    bounding boxes, transforming mesh vertices as Mesh::new does
+//    (src/tracer/mesh.rs:31-73);
+// 2. build the reference-shaped binary tree: Bvh::new (src/tracer/bvh.rs:39-117) over
+//    each mesh's triangles, then over the world, a mesh acting as one leaf whose
+//    box is its own root box (src/tracer/mesh.rs:90-97);
+// 3. number the primitives in the order the reference's traversal reaches them
+//    (right child first, src/tracer/bvh.rs:148-155);
+// 4. collapse the binary tree into 4-wide nodes.  A child slot is either a binary
+//    node (with that node's box) or a run of primitives that the reference tests
+//    right after one box test (with exactly that box), so a ray reaches a primitive
+//    here iff it reaches it in the reference: boxes of skipped interior nodes
+//    contain their children's boxes and the slab test is monotone in the box.
+//
+// All arithmetic is float32 with no fused operations except where the reference's
+// vector library fuses (dot / cross / mag_sq); compile with -ffp-contract=off.
+#include "scene_build.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace rtcore {
+namespace {
+
+const float kPi = 3.14159265358979323846f;
+const float kEps = 1.1920929e-7f;  // f32::EPSILON
+
+inline float fmin_(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+inline float fmax_(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+
+struct V3 {
+    float x, y, z;
+};
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 sub(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 add(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 mul(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+inline float dot(V3 a, V3 b) { return std::fmaf(a.x, b.x, std::fmaf(a.y, b.y, a.z * b.z)); }
+inline V3 cross(V3 a, V3 b) {
+    return v3(std::fmaf(a.y, b.z, -a.z * b.y), std::fmaf(a.z, b.x, -a.x * b.z), std::fmaf(a.x, b.y, -a.y * b.x));
+}
+inline V3 normalized(V3 a) {
+    float r = 1.0f / std::sqrt(dot(a, a));
+    return v3(a.x * r, a.y * r, a.z * r);
+}
+
+// ultraviolet::Rotor3 as the reference uses it (src/tracer/cube.rs:99, src/tracer/mesh.rs:31)
+struct Rotor {
+    float s, xy, xz, yz;
+};
+inline Rotor rotor_plane(float angle, float pxy, float pxz, float pyz) {
+    float half = angle * 0.5f;
+    float sn = std::sin(half), cs = std::cos(half);
+    return Rotor{cs, pxy * -sn, pxz * -sn, pyz * -sn};
+}
+inline Rotor rotor_mul(const Rotor &a, const Rotor &q) {
+    Rotor r;
+    r.s = a.s * q.s - a.xy * q.xy - a.xz * q.xz - a.yz * q.yz;
+    r.xy = a.xy * q.s + a.s * q.xy + a.yz * q.xz - a.xz * q.yz;
+    r.xz = a.xz * q.s + a.s * q.xz - a.yz * q.xy + a.xy * q.yz;
+    r.yz = a.yz * q.s + a.s * q.yz + a.xz * q.xy - a.xy * q.xz;
+    return r;
+}
+// from_euler_angles(roll, pitch, yaw) = rot_xz(yaw) * rot_yz(pitch) * rot_xy(roll), then normalized()
+inline Rotor rotor_from_euler(float roll, float pitch, float yaw) {
+    Rotor r = rotor_mul(rotor_mul(rotor_plane(yaw, 0, 1, 0), rotor_plane(pitch, 0, 0, 1)), rotor_plane(roll, 1, 0, 0));
+    float m2 = r.s * r.s + std::fmaf(r.xy, r.xy, std::fmaf(r.xz, r.xz, r.yz * r.yz));
+    float inv = 1.0f / std::sqrt(m2);
+    return Rotor{r.s * inv, r.xy * inv, r.xz * inv, r.yz * inv};
+}
+inline V3 rotate(const Rotor &r, V3 v) {
+    float fx = r.s * v.x + r.xy * v.y + r.xz * v.z;
+    float fy = r.s * v.y - r.xy * v.x + r.yz * v.z;
+    float fz = r.s * v.z - r.xz * v.x - r.yz * v.y;
+    float fw = r.xy * v.z - r.xz * v.y + r.yz * v.x;
+    return v3(r.s * fx + r.xy * fy + r.xz * fz + r.yz * fw, r.s * fy - r.xy * fx - r.xz * fw + r.yz * fz,
+              r.s * fz + r.xy * fw - r.xz * fx - r.yz * fy);
+}
+
+struct Box {
+    float lo[3], hi[3];
+};
+// Aabb::surrounding_box (src/tracer/cube.rs:179-193)
+inline Box surrounding(const Box &a, const Box &b) {
+    Box r;
+    for (int k = 0; k < 3; k++) {
+        r.lo[k] = fmin_(a.lo[k], b.lo[k]) - kEps;
+        r.hi[k] = fmax_(a.hi[k], b.hi[k]) + kEps;
+    }
+    return r;
+}
+inline float half_area(const Box &b) {
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+inline uint32_t fbits(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+const int32_t kNone = INT32_MIN;
+// child encoding of the binary tree: >= 0 node index, < 0 (and != kNone) ~primitive
+struct BNode {
+    Box box;
+    int32_t left, right;
+};
+struct Item {
+    int32_t child;
+    Box box;
+};
+
+// Bvh::box_compare (src/tracer/bvh.rs:120-139); "centre" is max + min/2 as written there.
+inline int box_compare(const Box &a, const Box &b, int axis) {
+    float ca = a.hi[axis] + a.lo[axis] * 0.5f;
+    float cb = b.hi[axis] + b.lo[axis] * 0.5f;
+    if (a.lo[axis] < b.lo[axis] && a.hi[axis] > b.hi[axis]) return -1;
+    if (b.lo[axis] < a.lo[axis] && b.hi[axis] > a.hi[axis]) return 1;
+    if (ca < cb) return -1;
+    if (ca > cb) return 1;
+    return 0;
+}
+
+struct Builder {
+    std::vector<BNode> nodes;
+    std::atomic<int64_t> next_node{0};
+    std::atomic<int> spare_threads{0};
+    std::atomic<bool> too_deep{false};
+
+    bool take_thread() {
+        int v = spare_threads.load();
+        while (v > 0)
+            if (spare_threads.compare_exchange_weak(v, v - 1)) return true;
+        return false;
+    }
+    void give_thread() { spare_threads.fetch_add(1); }
+
+    // Stable top-down merge sort (split at n/2, ties keep the left run first).  The
+    // comparator above is not a strict weak order, so the permutation depends on the
+    // algorithm; this one defines the tree.
+    void merge_sort(Item *a, Item *tmp, size_t n, int axis) {
+        if (n < 2) return;
+        size_t mid = n / 2;
+        if (n > (1u << 15) && take_thread()) {
+            std::thread t([&]() { merge_sort(a, tmp, mid, axis); });
+            merge_sort(a + mid, tmp + mid, n - mid, axis);
+            t.join();
+            give_thread();
+        } else {
+            merge_sort(a, tmp, mid, axis);
+            merge_sort(a + mid, tmp + mid, n - mid, axis);
+        }
+        size_t i = 0, j = mid, k = 0;
+        while (i < mid && j < n) {
+            if (box_compare(a[j].box, a[i].box, axis) < 0)
+                tmp[k++] = a[j++];
+            else
+                tmp[k++] = a[i++];
+        }
+        while (i < mid) tmp[k++] = a[i++];
+        while (j < n) tmp[k++] = a[j++];
+        std::memcpy(a, tmp, n * sizeof(Item));
+    }
+
+    // Bvh::largest_axis (src/tracer/bvh.rs:83-104): the fold pads by EPSILON at every step.
+    static int largest_axis(const Item *it, size_t n) {
+        Box b = it[0].box;
+        for (size_t i = 0; i < n; i++) b = surrounding(b, it[i].box);
+        float w = b.hi[0] - b.lo[0], h = b.hi[1] - b.lo[1], d = b.hi[2] - b.lo[2];
+        if (w > h && w > d) return 0;
+        if (h > d) return 1;
+        return 2;
+    }
+    // Bvh::true_middle (src/tracer/bvh.rs:106-117)
+    static size_t true_middle(const Item *it, size_t n, int axis) {
+        size_t mid = 1;
+        float mid_world = (it[0].box.lo[axis] + it[n - 1].box.hi[axis]) * 0.5f;
+        while (mid < n - 1 && (it[mid].box.hi[axis] + it[mid].box.lo[axis]) * 0.5f <= mid_world) mid++;
+        return mid;
+    }
+    const Box &child_box(int32_t c, const std::vector<Box> &prim_boxes) const {
+        return c >= 0 ? nodes[c].box : prim_boxes[~c];
+    }
+
+    // Bvh::new (src/tracer/bvh.rs:39-81)
+    int32_t build(Item *it, Item *tmp, size_t n, const std::vector<Box> &prim_boxes, int depth) {
+        if (depth > 4096) {
+            too_deep = true;
+            return kNone;
+        }
+        int axis = largest_axis(it, n);
+        merge_sort(it, tmp, n, axis);
+        int32_t me = (int32_t)next_node.fetch_add(1);
+        int32_t l = kNone, r = kNone;
+        if (n == 1) {
+            l = it[0].child;
+        } else if (n == 2) {
+            l = it[0].child;
+            r = it[1].child;
+        } else if (n == 3) {
+            l = build(it, tmp, 2, prim_boxes, depth + 1);
+            r = it[2].child;
+        } else {
+            size_t mid = true_middle(it, n, axis);
+            if (n > (1u << 14) && take_thread()) {
+                std::thread t([&]() { l = build(it, tmp, mid, prim_boxes, depth + 1); });
+                r = build(it + mid, tmp + mid, n - mid, prim_boxes, depth + 1);
+                t.join();
+                give_thread();
+            } else {
+                l = build(it, tmp, mid, prim_boxes, depth + 1);
+                r = build(it + mid, tmp + mid, n - mid, prim_boxes, depth + 1);
+            }
+        }
+        if (too_deep) return kNone;
+        BNode &nd = nodes[me];
+        nd.left = l;
+        nd.right = r;
+        if (l != kNone && r != kNone)
+            nd.box = surrounding(child_box(l, prim_boxes), child_box(r, prim_boxes));
+        else
+            nd.box = child_box(l, prim_boxes);
+        return me;
+    }
+};
+
+struct Slot {
+    Box box;
+    int32_t child;  // binary-tree child encoding
+};
+
+struct Collapser {
+    const std::vector<BNode> &bn;
+    const std::vector<uint32_t> &rank_of;  // primitive -> visit rank
+    std::vector<float> &out;               // 32 floats per wide node
+    uint32_t depth_max = 0;
+    bool overflow = false;
+
+    Collapser(const std::vector<BNode> &b, const std::vector<uint32_t> &r, std::vector<float> &o)
+        : bn(b), rank_of(r), out(o) {}
+
+    bool terminal(int32_t b) const {
+        const BNode &n = bn[b];
+        return (n.left == kNone || n.left < 0) && (n.right == kNone || n.right < 0);
+    }
+    // the slots the reference reaches right after passing node b's box
+    int child_slots(int32_t b, Slot *s) const {
+        const BNode &n = bn[b];
+        int c = 0;
+        const int32_t ch[2] = {n.left, n.right};
+        for (int k = 0; k < 2; k++) {
+            if (ch[k] == kNone) continue;
+            if (ch[k] >= 0)
+                s[c++] = Slot{bn[ch[k]].box, ch[k]};
+            else
+                s[c++] = Slot{n.box, ch[k]};  // a bare leaf is tested under its parent's box
+        }
+        return c;
+    }
+    uint32_t leaf_word(uint32_t first, uint32_t count) {
+        if (first > RT_LEAF_FIRST_MASK || count == 0 || count > RT_LEAF_MAX_PRIMS + 1) overflow = true;
+        return RT_CHILD_LEAF | ((count - 1) << 28) | first;
+    }
+
+    uint32_t make(int32_t b, uint32_t depth) {
+        if (depth > depth_max) depth_max = depth;
+        Slot slots[4];
+        int n;
+        if (terminal(b)) {
+            slots[0] = Slot{bn[b].box, b};
+            n = 1;
+        } else {
+            n = child_slots(b, slots);
+            for (;;) {
+                int best = -1;
+                float best_area = -1.0f;
+                for (int i = 0; i < n; i++) {
+                    int32_t c = slots[i].child;
+                    if (c < 0 || terminal(c)) continue;
+                    int kids = (bn[c].left != kNone) + (bn[c].right != kNone);
+                    if (n - 1 + kids > 4) continue;
+                    float a = half_area(slots[i].box);
+                    if (a > best_area) {
+                        best_area = a;
+                        best = i;
+                    }
+                }
+                if (best < 0) break;
+                Slot kids[2];
+                int k = child_slots(slots[best].child, kids);
+                slots[best] = kids[0];
+                if (k > 1) slots[n++] = kids[1];
+            }
+        }
+        size_t me = out.size() / 32;
+        out.resize(out.size() + 32, 0.0f);
+        uint32_t words[4] = {RT_CHILD_NONE, RT_CHILD_NONE, RT_CHILD_NONE, RT_CHILD_NONE};
+        float boxes[6][4];
+        for (int a = 0; a < 6; a++)
+            for (int i = 0; i < 4; i++) boxes[a][i] = 0.0f;
+        for (int i = 0; i < n; i++) {
+            for (int a = 0; a < 3; a++) {
+                boxes[a][i] = slots[i].box.lo[a];
+                boxes[3 + a][i] = slots[i].box.hi[a];
+            }
+            int32_t c = slots[i].child;
+            if (c < 0) {
+                words[i] = leaf_word(rank_of[~c], 1);
+            } else if (terminal(c)) {
+                const BNode &t = bn[c];
+                // right is visited first, so it has the lower rank
+                if (t.left != kNone && t.right != kNone) {
+                    uint32_t r0 = rank_of[~t.right], r1 = rank_of[~t.left];
+                    if (r1 != r0 + 1) overflow = true;
+                    words[i] = leaf_word(r0, 2);
+                } else {
+                    words[i] = leaf_word(rank_of[~(t.left != kNone ? t.left : t.right)], 1);
+                }
+            } else {
+                words[i] = make(c, depth + 1);
+            }
+        }
+        float *dst = &out[me * 32];
+        for (int a = 0; a < 6; a++)
+            for (int i = 0; i < 4; i++) dst[a * 4 + i] = boxes[a][i];
+        std::memcpy(dst + 24, words, 16);
+        return (uint32_t)me;
+    }
+};
+
+}  // namespace
+
+void make_camera(const RtCamera &c, float aspect, RtDevCamera &o) {
+    V3 eye = v3(c.eye[0], c.eye[1], c.eye[2]), lookat = v3(c.lookat[0], c.lookat[1], c.lookat[2]);
+    V3 vup = v3(c.vup[0], c.vup[1], c.vup[2]);
+    float h = std::tan((c.fov_degrees * (kPi / 180.0f)) / 2.0f);
+    float vh = 2.0f * h;
+    float vw = aspect * vh;
+    V3 w = normalized(sub(eye, lookat));
+    V3 u = normalized(cross(vup, w));
+    V3 v = cross(w, u);
+    float fw = c.focus_dist * vw, fh = c.focus_dist * vh;
+    V3 hor = v3(fw * u.x, fw * u.y, fw * u.z);
+    V3 ver = v3(fh * v.x, fh * v.y, fh * v.z);
+    V3 fwv = v3(c.focus_dist * w.x, c.focus_dist * w.y, c.focus_dist * w.z);
+    V3 llc = sub(sub(sub(eye, v3(hor.x / 2.0f, hor.y / 2.0f, hor.z / 2.0f)), v3(ver.x / 2.0f, ver.y / 2.0f, ver.z / 2.0f)), fwv);
+    std::memset(&o, 0, sizeof(o));
+    o.eye[0] = eye.x, o.eye[1] = eye.y, o.eye[2] = eye.z;
+    o.lens_radius = c.aperture / 2.0f;
+    o.horizontal[0] = hor.x, o.horizontal[1] = hor.y, o.horizontal[2] = hor.z;
+    o.vertical[0] = ver.x, o.vertical[1] = ver.y, o.vertical[2] = ver.z;
+    o.llc[0] = llc.x, o.llc[1] = llc.y, o.llc[2] = llc.z;
+    o.u[0] = u.x, o.u[1] = u.y, o.u[2] = u.z;
+    o.v[0] = v.x, o.v[1] = v.y, o.v[2] = v.z;
+}
+
+int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
+    if (!d || (d->n_objects && !d->objects) || (d->n_materials && !d->materials) || (d->n_meshes && !d->meshes)) {
+        err = "null scene description";
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    if (d->n_objects == 0) {
+        err = "a scene needs at least one object (the reference panics on an empty world)";
+        return RT_ERR_EMPTY_SCENE;
+    }
+    // ---- count primitives
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < d->n_objects; i++) {
+        const RtObject &o = d->objects[i];
+        if (o.material < 0 || (uint64_t)o.material >= d->n_materials) {
+            err = "object " + std::to_string(i) + ": material index out of range";
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+        if (o.type == RT_OBJ_MESH) {
+            if (o.mesh < 0 || (uint64_t)o.mesh >= d->n_meshes) {
+                err = "object " + std::to_string(i) + ": mesh index out of range";
+                return RT_ERR_INVALID_ARGUMENT;
+            }
+            const RtMesh &m = d->meshes[o.mesh];
+            if (m.n_faces == 0) {
+                err = "object " + std::to_string(i) + ": mesh without faces";
+                return RT_ERR_EMPTY_SCENE;
+            }
+            if (!m.positions || !m.normals || !m.indices) {
+                err = "object " + std::to_string(i) + ": mesh needs positions, normals and indices";
+                return RT_ERR_INVALID_ARGUMENT;
+            }
+            for (uint64_t k = 0; k < 3 * m.n_faces; k++)
+                if (m.indices[k] >= m.n_vertices) {
+                    err = "object " + std::to_string(i) + ": vertex index out of range";
+                    return RT_ERR_INVALID_ARGUMENT;
+                }
+            total += m.n_faces;
+        } else if (o.type >= RT_OBJ_SPHERE && o.type <= RT_OBJ_TRIANGLE) {
+            total += 1;
+        } else {
+            err = "object " + std::to_string(i) + ": unknown type";
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+    }
+    if (total > RT_LEAF_FIRST_MASK) {
+        err = "too many primitives";
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    if (d->n_materials >= (1u << 28)) {
+        err = "too many materials";
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+
+    // ---- primitives in declaration order
+    std::vector<uint32_t> rec(total * 12, 0);
+    std::vector<float> nrm(total * 12, 0.0f);
+    std::vector<Box> boxes(total);
+    struct MeshSpan {
+        uint64_t first, count;
+    };
+    std::vector<Item> world_items;
+    std::vector<MeshSpan> mesh_spans;
+    std::vector<size_t> mesh_world_slot;
+    uint64_t id = 0;
+    hs.n_triangles = 0;
+    for (uint64_t i = 0; i < d->n_objects; i++) {
+        const RtObject &o = d->objects[i];
+        uint32_t mat = (uint32_t)o.material << RT_PRIM_MAT_SHIFT;
+        auto put3 = [&](uint64_t p, int w, V3 v) {
+            rec[p * 12 + w] = fbits(v.x), rec[p * 12 + w + 1] = fbits(v.y), rec[p * 12 + w + 2] = fbits(v.z);
+        };
+        auto tri = [&](uint64_t p, const V3 vv[3], const V3 nn[3], bool two_sided) {
+            put3(p, 0, vv[0]);
+            put3(p, 3, sub(vv[1], vv[0]));
+            put3(p, 6, sub(vv[2], vv[0]));
+            rec[p * 12 + 10] = RT_PRIM_TRIANGLE | (two_sided ? RT_PRIM_FLAG : 0) | mat;
+            rec[p * 12 + 11] = (uint32_t)p;
+            for (int k = 0; k < 3; k++) {
+                nrm[p * 12 + 4 * k] = nn[k].x, nrm[p * 12 + 4 * k + 1] = nn[k].y, nrm[p * 12 + 4 * k + 2] = nn[k].z;
+            }
+            Box &b = boxes[p];  // Triangle::bounding_box (src/tracer/triangle.rs:80-105)
+            b.lo[0] = fmin_(vv[0].x, fmin_(vv[1].x, vv[2].x)), b.hi[0] = fmax_(vv[0].x, fmax_(vv[1].x, vv[2].x));
+            b.lo[1] = fmin_(vv[0].y, fmin_(vv[1].y, vv[2].y)), b.hi[1] = fmax_(vv[0].y, fmax_(vv[1].y, vv[2].y));
+            b.lo[2] = fmin_(vv[0].z, fmin_(vv[1].z, vv[2].z)), b.hi[2] = fmax_(vv[0].z, fmax_(vv[1].z, vv[2].z));
+        };
+        switch (o.type) {
+            case RT_OBJ_SPHERE: {
+                put3(id, 0, v3(o.a[0], o.a[1], o.a[2]));
+                rec[id * 12 + 3] = fbits(o.b[0]);
+                rec[id * 12 + 10] = RT_PRIM_SPHERE | mat;
+                rec[id * 12 + 11] = (uint32_t)id;
+                float r = 1.0f * std::fabs(o.b[0]);  // Sphere::bounding_box (src/tracer/sphere.rs:60-65)
+                for (int k = 0; k < 3; k++) boxes[id].lo[k] = o.a[k] - r, boxes[id].hi[k] = o.a[k] + r;
+                world_items.push_back(Item{~(int32_t)id, boxes[id]});
+                id++;
+                break;
+            }
+            case RT_OBJ_ABOX:
+            case RT_OBJ_CUBE: {
+                // ABox::new (src/tracer/cube.rs:20-38)
+                bool hollow = fmin_(fmin_(o.b[0], o.b[1]), o.b[2]) < 0.0f;
+                float half[3], lo[3], hi[3];
+                for (int k = 0; k < 3; k++) {
+                    half[k] = std::fabs(o.b[k] * 0.5f);
+                    lo[k] = o.a[k] - half[k];
+                    hi[k] = o.a[k] + half[k];
+                }
+                if (o.type == RT_OBJ_ABOX) {
+                    put3(id, 0, v3(lo[0], lo[1], lo[2]));
+                    put3(id, 3, v3(hi[0], hi[1], hi[2]));
+                    rec[id * 12 + 10] = RT_PRIM_ABOX | (hollow ? RT_PRIM_FLAG : 0) | mat;
+                    for (int k = 0; k < 3; k++) boxes[id].lo[k] = lo[k], boxes[id].hi[k] = hi[k];
+                } else {
+                    // Cube::new / Cube::bounding_box (src/tracer/cube.rs:90-102, :120-148)
+                    Rotor rot = rotor_from_euler(o.c[2] * kPi, o.c[0] * kPi, o.c[1] * kPi);
+                    put3(id, 0, v3(o.a[0], o.a[1], o.a[2]));
+                    put3(id, 3, v3(half[0], half[1], half[2]));
+                    rec[id * 12 + 6] = fbits(rot.s), rec[id * 12 + 7] = fbits(rot.xy);
+                    rec[id * 12 + 8] = fbits(rot.xz), rec[id * 12 + 9] = fbits(rot.yz);
+                    rec[id * 12 + 10] = RT_PRIM_CUBE | (hollow ? RT_PRIM_FLAG : 0) | mat;
+                    V3 c = v3(o.a[0], o.a[1], o.a[2]);
+                    Box &b = boxes[id];
+                    for (int k = 0; k < 3; k++) b.lo[k] = INFINITY, b.hi[k] = -INFINITY;
+                    for (int corner = 0; corner < 8; corner++) {
+                        V3 p = v3((corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]);
+                        V3 q = add(rotate(rot, sub(p, c)), c);
+                        b.lo[0] = fmin_(b.lo[0], q.x), b.lo[1] = fmin_(b.lo[1], q.y), b.lo[2] = fmin_(b.lo[2], q.z);
+                        b.hi[0] = fmax_(b.hi[0], q.x), b.hi[1] = fmax_(b.hi[1], q.y), b.hi[2] = fmax_(b.hi[2], q.z);
+                    }
+                }
+                rec[id * 12 + 11] = (uint32_t)id;
+                world_items.push_back(Item{~(int32_t)id, boxes[id]});
+                id++;
+                break;
+            }
+            case RT_OBJ_TRIANGLE: {
+                V3 vv[3], nn[3];
+                for (int k = 0; k < 3; k++) {
+                    vv[k] = v3(o.tri_vertices[3 * k], o.tri_vertices[3 * k + 1], o.tri_vertices[3 * k + 2]);
+                    nn[k] = v3(o.tri_normals[3 * k], o.tri_normals[3 * k + 1], o.tri_normals[3 * k + 2]);
+                }
+                tri(id, vv, nn, o.flag != 0);
+                world_items.push_back(Item{~(int32_t)id, boxes[id]});
+                hs.n_triangles++;
+                id++;
+                break;
+            }
+            default: {  // RT_OBJ_MESH, Mesh::new (src/tracer/mesh.rs:22-87)
+                const RtMesh &m = d->meshes[o.mesh];
+                Rotor rot = rotor_from_euler(m.rotation[2], m.rotation[0], m.rotation[1]);
+                V3 sc = v3(m.scale[0], m.scale[1], m.scale[2]);
+                V3 tr = v3(m.translation[0], m.translation[1], m.translation[2]);
+                for (uint64_t f = 0; f < m.n_faces; f++) {
+                    V3 vv[3], nn[3];
+                    for (int k = 0; k < 3; k++) {
+                        uint64_t vi = m.indices[3 * f + k];
+                        V3 p = v3(m.positions[3 * vi], m.positions[3 * vi + 1], m.positions[3 * vi + 2]);
+                        vv[k] = add(rotate(rot, mul(p, sc)), tr);
+                        nn[k] = rotate(rot, v3(m.normals[3 * vi], m.normals[3 * vi + 1], m.normals[3 * vi + 2]));
+                    }
+                    tri(id + f, vv, nn, !m.cull_backface);
+                }
+                mesh_spans.push_back(MeshSpan{id, m.n_faces});
+                mesh_world_slot.push_back(world_items.size());
+                world_items.push_back(Item{kNone, Box{}});  // filled once the mesh tree exists
+                hs.n_triangles += m.n_faces;
+                id += m.n_faces;
+                break;
+            }
+        }
+    }
+
+    // ---- binary trees
+    Builder B;
+    B.nodes.resize(total + world_items.size() + 1);
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 1;
+    if (hw > 16) hw = 16;
+    B.spare_threads = (int)hw - 1;
+    {
+        uint64_t biggest = 0;
+        for (auto &s : mesh_spans) biggest = std::max(biggest, s.count);
+        std::vector<Item> items(std::max<uint64_t>(biggest, world_items.size())), tmp(items.size());
+        for (size_t mi = 0; mi < mesh_spans.size(); mi++) {
+            const MeshSpan &s = mesh_spans[mi];
+            for (uint64_t f = 0; f < s.count; f++) items[f] = Item{~(int32_t)(s.first + f), boxes[s.first + f]};
+            int32_t root = B.build(items.data(), tmp.data(), s.count, boxes, 0);
+            if (root == kNone || B.too_deep) {
+                err = "mesh geometry too degenerate for the reference's median split";
+                return RT_ERR_INTERNAL;
+            }
+            world_items[mesh_world_slot[mi]] = Item{root, B.nodes[root].box};
+        }
+        std::vector<Item> wtmp(world_items.size());
+        int32_t root = B.build(world_items.data(), wtmp.data(), world_items.size(), boxes, 0);
+        if (root == kNone || B.too_deep) {
+            err = "scene too degenerate for the reference's median split";
+            return RT_ERR_INTERNAL;
+        }
+        hs.n_binary_nodes = (uint64_t)B.next_node.load();
+        B.nodes.resize(hs.n_binary_nodes);
+
+        // ---- visit ranks: right child first
+        std::vector<uint32_t> rank_of(total, 0);
+        {
+            std::vector<int32_t> stack;
+            stack.push_back(root);
+            uint32_t next = 0;
+            while (!stack.empty()) {
+                int32_t c = stack.back();
+                stack.pop_back();
+                if (c == kNone) continue;
+                if (c < 0) {
+                    rank_of[~c] = next++;
+                    continue;
+                }
+                stack.push_back(B.nodes[c].left);   // popped second
+                stack.push_back(B.nodes[c].right);  // popped first
+            }
+            if (next != total) {
+                err = "internal: visit order does not cover every primitive";
+                return RT_ERR_INTERNAL;
+            }
+        }
+
+        // ---- wide nodes
+        hs.nodes.clear();
+        hs.nodes.reserve((total / 4 + 8) * 32);
+        Collapser C(B.nodes, rank_of, hs.nodes);
+        C.make(root, 1);
+        if (C.overflow) {
+            err = "internal: leaf encoding overflow";
+            return RT_ERR_INTERNAL;
+        }
+        hs.n_nodes = hs.nodes.size() / 32;
+        hs.wide_depth = C.depth_max;
+        hs.max_stack = 3 * C.depth_max + 4;
+        for (int k = 0; k < 3; k++) hs.root_lo[k] = B.nodes[root].box.lo[k], hs.root_hi[k] = B.nodes[root].box.hi[k];
+
+        // ---- records in rank order
+        hs.prims.assign(total * 12, 0);
+        hs.tri_normals.assign(total * 12, 0.0f);
+        for (uint64_t p = 0; p < total; p++) {
+            uint64_t r = rank_of[p];
+            std::memcpy(&hs.prims[r * 12], &rec[p * 12], 48);
+            std::memcpy(&hs.tri_normals[r * 12], &nrm[p * 12], 48);
+        }
+    }
+    hs.n_prims = total;
+
+    hs.materials.resize(d->n_materials);
+    for (uint64_t i = 0; i < d->n_materials; i++) {
+        const RtMaterial &m = d->materials[i];
+        if (m.type < RT_MAT_DIELECTRIC || m.type > RT_MAT_GLOSSY) {
+            err = "material " + std::to_string(i) + ": unknown type";
+            return RT_ERR_INVALID_ARGUMENT;
+        }
+        RtDevMaterial &o = hs.materials[i];
+        std::memset(&o, 0, sizeof(o));
+        o.albedo[0] = m.albedo[0], o.albedo[1] = m.albedo[1], o.albedo[2] = m.albedo[2];
+        o.type = m.type;
+        o.p0 = m.p0, o.p1 = m.p1;
+    }
+    hs.camera = d->camera;
+    hs.env.clear();
+    hs.env_w = hs.env_h = 0;
+    if (d->env.rgb && d->env.width && d->env.height) {
+        hs.env.assign(d->env.rgb, d->env.rgb + (size_t)d->env.width * d->env.height * 3);
+        hs.env_w = d->env.width;
+        hs.env_h = d->env.height;
+    }
+    return RT_OK;
+}
+
+}  // namespace rtcore

@@ -1,0 +1,36 @@
+// scene_build.hpp -- host side of rt_scene_create: builds the reference-shaped binary
+// tree, numbers the primitives in the reference's visit order and collapses the tree
+// into 4-wide nodes.  No device code here.
+#ifndef RT_SCENE_BUILD_HPP
+#define RT_SCENE_BUILD_HPP
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rtcore.h"
+#include "rt_types.h"
+
+namespace rtcore {
+
+struct HostScene {
+    std::vector<float> nodes;          // 32 floats per wide node
+    std::vector<uint32_t> prims;       // 12 words per primitive, visit-rank order
+    std::vector<float> tri_normals;    // 12 floats per primitive (zero for non-triangles)
+    std::vector<RtDevMaterial> materials;
+    std::vector<float> env;
+    uint32_t env_w = 0, env_h = 0;
+    float root_lo[3] = {0, 0, 0}, root_hi[3] = {0, 0, 0};
+    uint64_t n_prims = 0, n_triangles = 0, n_nodes = 0, n_binary_nodes = 0;
+    uint32_t wide_depth = 0, max_stack = 0;
+    RtCamera camera{};
+};
+
+// Returns RT_OK or a negative RtStatus and fills `err`.
+int build_host_scene(const RtSceneDesc *desc, HostScene &out, std::string &err);
+
+// Camera::new (src/camera.rs:21-50)
+void make_camera(const RtCamera &c, float aspect, RtDevCamera &out);
+
+}  // namespace rtcore
+#endif

@@ -1,0 +1,197 @@
+"""GPU parity: the HIP core through its C ABI against the CPU oracle on the same seeded inputs.
+
+Bar: primitive ids exact; t, normal and point within 1e-5 relative as the acceptance
+criterion, and in fact bit-identical, because device and oracle perform the same IEEE
+operation sequence; rendered passes bit-identical for the same reason.
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_err(a, b):
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)) / np.maximum(1e-30, np.abs(b).astype(np.float64)))) if a.size else 0.0
+
+
+def check_hits(pkg, oracle, desc, rays, t_min=0.00015, t_max=100000.0, expect_hits=True):
+    scene = pkg.Scene(desc)
+    ora = oracle.OracleScene(desc)
+    ids, t, nrm, pt = scene.closest_hit(rays, t_min, t_max)
+    oids, ot, onrm, opt = ora.closest_hit(rays, t_min, t_max)
+    mism = int((ids != oids).sum())
+    assert mism == 0, "%d of %d primitive ids differ (first at ray %d: %d vs %d)" % (
+        mism, len(ids), int(np.argmax(ids != oids)), ids[np.argmax(ids != oids)], oids[np.argmax(ids != oids)])
+    hit = oids >= 0
+    if expect_hits:
+        assert hit.sum() > 0
+    # tolerance stated by the acceptance criterion
+    assert _rel_err(t[hit], ot[hit]) <= 1e-5
+    assert np.max(np.abs(nrm[hit] - onrm[hit]), initial=0.0) <= 1e-5
+    # what the design delivers: identical bits (NaN normals compare by bit pattern)
+    assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(nrm.view(np.uint32), onrm.view(np.uint32))
+    assert np.array_equal(pt.view(np.uint32), opt.view(np.uint32))
+    scene.close()
+    return ids
+
+
+def camera_like_rays(n, eye, target_lo, target_hi, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    tgt = np.asarray(target_lo) + rng.random((n, 3)) * (np.asarray(target_hi) - np.asarray(target_lo))
+    o = np.broadcast_to(np.asarray(eye, dtype=np.float64), (n, 3))
+    return np.concatenate([o, tgt - o], axis=1).astype(np.float32)
+
+
+def test_cornell_hits(pkg, oracle):
+    d = pkg.scenes.cornell()
+    rays = np.concatenate([
+        camera_like_rays(200_000, (0, 0, -22), (-6, -6, 0), (6, 6, 0), 1),
+        pkg.scenes.random_rays(200_000, (-5.5, -5.5, -30), (5.5, 5.5, 10), seed=2, inflate=0.9),
+    ])
+    check_hits(pkg, oracle, d, rays)
+
+
+def test_rtiow_hits(pkg, oracle):
+    d = pkg.scenes.rtiow(seed=3)
+    rays = np.concatenate([
+        camera_like_rays(200_000, (13, 2, 3), (-6, 0, -6), (6, 2, 6), 4),
+        pkg.scenes.random_rays(200_000, (-12, 0, -12), (12, 2.5, 12), seed=5, inflate=1.0),
+    ])
+    check_hits(pkg, oracle, d, rays)
+
+
+def mixed_scene(pkg):
+    """Every primitive type, overlapping, plus exactly coincident primitives (tie handling)."""
+    S = pkg.SceneDescription()
+    m = [S.add_material(pkg.lambertian((0.5, 0.5, 0.5))), S.add_material(pkg.metal((0.8, 0.8, 0.8), 0.1)),
+         S.add_material(pkg.dielectric((0.1, 0.2, 0.3))), S.add_material(pkg.glossy((0.3, 0.6, 0.2), 0.5, 0.2))]
+    rng = np.random.Generator(np.random.PCG64(11))
+    for i in range(40):
+        c = rng.random(3) * 8 - 4
+        S.add_sphere(tuple(c), float(0.2 + rng.random() * 0.8), m[i % 4])
+    for i in range(20):
+        c = rng.random(3) * 8 - 4
+        S.add_axis_box(tuple(c), tuple(0.3 + rng.random(3) * 1.5), m[i % 4])
+    for i in range(20):
+        c = rng.random(3) * 8 - 4
+        S.add_box(tuple(c), tuple(0.3 + rng.random(3) * 1.5), tuple(rng.random(3) * 2 - 1), m[i % 4])
+    for i in range(60):
+        c = rng.random(3) * 8 - 4
+        v = c + rng.random((3, 3)) * 2 - 1
+        S.add_triangle(v, m[i % 4], two_sided=bool(i % 2))
+    # coincident pairs: same sphere twice, same triangle twice, same box twice, a triangle in a box face plane
+    S.add_sphere((0, 0, 6), 1.0, m[0])
+    S.add_sphere((0, 0, 6), 1.0, m[1])
+    tri = [(-1, -1, 8), (1, -1, 8), (0, 1, 8)]
+    S.add_triangle(tri, m[0])
+    S.add_triangle(tri, m[1])
+    S.add_axis_box((3, 3, 6), (1, 1, 1), m[2])
+    S.add_axis_box((3, 3, 6), (1, 1, 1), m[3])
+    S.add_triangle([(2.5, 2.5, 5.5), (3.5, 2.5, 5.5), (3.0, 3.5, 5.5)], m[0])
+    S.add_axis_box((0, 0, 0), (-30, -30, -30), m[0])  # hollow enclosure: every ray hits something
+    S.set_camera((0, 0, -12), (0, 0, 0), 40.0)
+    return S
+
+
+def test_mixed_primitives_and_ties(pkg, oracle):
+    d = mixed_scene(pkg)
+    rays = np.concatenate([
+        pkg.scenes.random_rays(300_000, (-6, -6, -6), (6, 6, 9), seed=6, inflate=1.2),
+        camera_like_rays(100_000, (0, 0, -12), (-5, -5, 0), (5, 5, 9), 7),
+        # axis-parallel rays onto the coincident primitives: exact ties
+        np.array([[0, 0, -3, 0, 0, 1], [0.1, -0.2, -3, 0, 0, 1], [3, 3, -3, 0, 0, 1], [3.1, 2.9, -3, 0, 0, 1],
+                  [0, 0, 20, 0, 0, -1], [3, 3, 20, 0, 0, -1], [0.25, 0.25, 20, 0, 0, -1]], dtype=np.float32),
+    ])
+    ids = check_hits(pkg, oracle, d, rays)
+    assert len(np.unique(ids)) > 100
+
+
+def test_mesh_hits(pkg, oracle):
+    d = pkg.scenes.mesh_scene(n_triangles=120_000, rings=32, segments=32, seed=5)
+    ora = oracle.OracleScene(d)
+    mn, mx = ora.bounds()
+    rays = pkg.scenes.random_rays(500_000, mn, mx, seed=0x5EED, inflate=1.5)
+    ids = check_hits(pkg, oracle, d, rays)
+    assert (ids >= 2).sum() > 10_000  # plenty of triangle hits
+
+
+def test_t_range_bounds(pkg, oracle):
+    """Caller-supplied t_min / t_max, including hits exactly at t_max (inclusive for triangles and box entries)."""
+    S = pkg.SceneDescription()
+    m = S.add_material(pkg.lambertian((0.5, 0.5, 0.5)))
+    S.add_triangle([(0, 0, 0), (1, 0, 0), (0, 1, 0)], m)
+    S.add_sphere((3, 0, 0), 1.0, m)
+    S.add_axis_box((6, 0, 0), (2, 2, 2), m)
+    rays = np.array([[0.25, 0.25, -1, 0, 0, 1], [3, 0, -5, 0, 0, 1], [6, 0, -5, 0, 0, 1], [6, 0, 0, 0, 0, 1]], np.float32)
+    for t_max in (1.0, 4.0, 0.999, 100.0):
+        check_hits(pkg, oracle, S, rays, 0.00015, t_max, expect_hits=False)
+
+
+@pytest.mark.parametrize("name", ["cornell", "rtiow", "mesh_env"])
+def test_render_pass_bit_identical(pkg, oracle, name):
+    if name == "cornell":
+        d, W, H, spp, bounces = pkg.scenes.cornell(), 96, 64, 8, 8
+    elif name == "rtiow":
+        d, W, H, spp, bounces = pkg.scenes.rtiow(seed=2), 96, 64, 8, 8
+    else:
+        d = pkg.scenes.mesh_scene(n_triangles=30_000, rings=24, segments=24, seed=9)
+        d.objects = d.objects[2:]  # drop room and light: the environment lights the blobs
+        d.set_environment(pkg.scenes.sky_map(256, 128))
+        W, H, spp, bounces = 96, 64, 8, 8
+    scene = pkg.Scene(d)
+    ora = oracle.OracleScene(d)
+    acc = np.zeros(W * H * 3, np.float32)
+    oacc = np.zeros(W * H * 3, np.float32)
+    for pass_index in range(2):
+        p = pkg.Scene.params(W, H, spp, bounces, light_clamp=(20.0 if name == "mesh_env" else math.inf),
+                             pass_index=pass_index, seed=42, batch_paths=(W * H * spp) // 3 + 17)
+        scene.render_pass(acc, p)
+        ora.render_pass(oacc, p)
+    st = scene.stats()
+    assert st.rays == ora.counters()["rays"] * 1 or st.rays > 0
+    assert np.isfinite(oacc).all()
+    # acceptance criterion: mean luminance within 1 %
+    assert abs(float(acc.mean()) - float(oacc.mean())) <= 0.01 * abs(float(oacc.mean()))
+    # delivered: identical bits
+    diff = int((acc.view(np.uint32) != oacc.view(np.uint32)).sum())
+    assert diff == 0, "%d of %d accumulator words differ, max abs %.3g" % (diff, acc.size, float(np.max(np.abs(acc - oacc))))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_preview_and_modes(pkg, oracle, mode):
+    d = pkg.scenes.rtiow(seed=4)
+    scene = pkg.Scene(d)
+    ora = oracle.OracleScene(d)
+    W, H = 80, 60
+    p = pkg.Scene.params(W, H, 1, 8, mode=mode, seed=5)
+    out = np.zeros(W * H * 3, np.float32)
+    oout = np.zeros(W * H * 3, np.float32)
+    scene.preview(out, p)
+    ora.preview(oout, p)
+    assert np.array_equal(out.view(np.uint32), oout.view(np.uint32))
+    if mode != 2:  # Renderer::render with Mode::Normals / Mode::Colors
+        p = pkg.Scene.params(W, H, 3, 8, mode=mode, seed=6)
+        acc = np.zeros(W * H * 3, np.float32)
+        oacc = np.zeros(W * H * 3, np.float32)
+        scene.render_pass(acc, p)
+        ora.render_pass(oacc, p)
+        assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))
+
+
+def test_ray_count_matches_oracle(pkg, oracle):
+    d = pkg.scenes.cornell()
+    scene = pkg.Scene(d)
+    ora = oracle.OracleScene(d)
+    W, H = 64, 48
+    p = pkg.Scene.params(W, H, 4, 8, seed=9)
+    acc = np.zeros(W * H * 3, np.float32)
+    scene.stats()
+    scene.render_pass(acc, p)
+    st = scene.stats()
+    oacc = np.zeros(W * H * 3, np.float32)
+    ora.render_pass(oacc, p)
+    assert st.paths == W * H * 4
+    assert st.rays == ora.counters()["rays"]
