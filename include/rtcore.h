@@ -202,6 +202,9 @@ const char *rt_version(void);
  * as src/io.rs:200 takes it from the arguments).
  */
 int rt_scene_create(const RtSceneDesc *desc, RtScene **out);
+/* Host-only dry run of rt_scene_create: validates the description, builds and collapses the
+ * tree, fills `info` (device_bytes = what the scene would hold) and frees everything.  Needs no device. */
+int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info);
 int rt_scene_destroy(RtScene *scene);
 int rt_scene_info(const RtScene *scene, RtSceneInfo *info);
 int rt_scene_stats(const RtScene *scene, RtStats *stats);

@@ -137,6 +137,7 @@ SYMBOLS = {
     "rt_last_error": (C.c_char_p, []),
     "rt_version": (C.c_char_p, []),
     "rt_scene_create": (C.c_int, [C.POINTER(RtSceneDesc), C.POINTER(_VP)]),
+    "rt_scene_validate": (C.c_int, [C.POINTER(RtSceneDesc), C.POINTER(RtSceneInfo)]),
     "rt_scene_destroy": (C.c_int, [_VP]),
     "rt_scene_info": (C.c_int, [_VP, C.POINTER(RtSceneInfo)]),
     "rt_scene_stats": (C.c_int, [_VP, C.POINTER(RtStats)]),

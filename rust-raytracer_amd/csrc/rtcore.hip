@@ -618,6 +618,26 @@ int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
     return RT_OK;
 }
 
+int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info) {
+    if (!desc || !info) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    rtcore::HostScene h;
+    std::string err;
+    int rc = rtcore::build_host_scene(desc, h, err);
+    if (rc) return fail(rc, err);
+    std::memset(info, 0, sizeof(*info));
+    info->n_primitives = h.n_prims;
+    info->n_triangles = h.n_triangles;
+    info->n_wide_nodes = h.n_nodes;
+    info->n_binary_nodes = h.n_binary_nodes;
+    info->wide_depth = h.wide_depth;
+    info->node_bytes = RT_NODE_FLOAT4S * 16;
+    info->primitive_bytes = RT_PRIM_FLOAT4S * 16;
+    info->device_bytes = (h.nodes.size() + h.prims.size() + h.tri_normals.size() + h.env.size()) * 4 +
+                         h.materials.size() * sizeof(RtDevMaterial);
+    for (int k = 0; k < 3; k++) info->bounds_min[k] = h.root_lo[k], info->bounds_max[k] = h.root_hi[k];
+    return RT_OK;
+}
+
 int rt_scene_destroy(RtScene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);

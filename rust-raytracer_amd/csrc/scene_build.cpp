@@ -534,7 +534,7 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
 
     // ---- binary trees
     Builder B;
-    B.nodes.resize(total + world_items.size() + 1);
+    B.nodes.resize(2 * (total + world_items.size()) + 2);  // a run of n items makes at most 2n - 1 nodes
     unsigned hw = std::thread::hardware_concurrency();
     if (hw == 0) hw = 1;
     if (hw > 16) hw = 16;
