@@ -243,6 +243,10 @@ int rt_closest_hit_batch_counted_device(RtScene *scene, const float *d_org_dir, 
 /* When nonzero, render passes time their stages with HIP events into RtStats (adds syncs). */
 int rt_set_stage_timing(RtScene *scene, int enabled);
 
+/* When nonzero, render passes use the counting closest-hit kernel: RtStats.node_visits / prim_tests
+ * are filled (slower; for measuring the bytes a ray touches, not for production). */
+int rt_set_counting(RtScene *scene, int enabled);
+
 /*
  * Host-side helpers that need no device: the reference's display transform,
  * kept here so a host without the Rust crate can drain the core.

@@ -152,6 +152,7 @@ SYMBOLS = {
         [_VP, _VP, C.c_float, C.c_float, C.c_size_t, _VP, _VP, _VP, _VP, _VP],
     ),
     "rt_set_stage_timing": (C.c_int, [_VP, C.c_int]),
+    "rt_set_counting": (C.c_int, [_VP, C.c_int]),
     "rt_to_rgb": (C.c_uint32, [_FP, C.c_float]),
 }
 

@@ -227,6 +227,13 @@ RT_DEV Best closest_hit(const RtSceneView &sc, const Ray &ray, float t_min, floa
     best.ties = false;
     const float4 *__restrict__ nodes = (const float4 *)sc.nodes;
     const float4 *__restrict__ prims = (const float4 *)sc.prims;
+    // A ray whose direction (or origin) is NaN in every component passes every box test of the
+    // reference (NaN-ignoring min/max leave t_min <= t_max) and fails every primitive test, so it
+    // would walk the whole tree only to miss.  Ray::new turns a zero or NaN direction into such a
+    // ray.  The result is known without the walk.
+    if ((ray.d.x != ray.d.x && ray.d.y != ray.d.y && ray.d.z != ray.d.z) ||
+        (ray.o.x != ray.o.x && ray.o.y != ray.o.y && ray.o.z != ray.o.z))
+        return best;
     F3 inv = f3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     {   // the root's own box (src/tracer/bvh.rs:144-147)
         F3 t0 = (f3(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2]) - ray.o) * inv;

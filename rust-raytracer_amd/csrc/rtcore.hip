@@ -372,6 +372,7 @@ struct RtScene {
     uint64_t work_paths = 0;
     uint32_t extend_blocks = 0;
     bool timing = false;
+    bool counting = false;
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
@@ -510,7 +511,7 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
         }
         int cur = 0;
         for (uint32_t b = 0; b < depth; b++) {
-            if ((rc = launch_extend(s, stream, st[cur].o, st[cur].d, counts + b, n, kTMin, kTMax, false))) return rc;
+            if ((rc = launch_extend(s, stream, st[cur].o, st[cur].d, counts + b, n, kTMin, kTMax, s->counting))) return rc;
             StageTimer tm(s, stream, 1);
             uint32_t blocks = std::min(blocks_for(n), (uint32_t)s->n_cus * 16u);
             if (first_hit_only) {
@@ -669,6 +670,12 @@ int rt_scene_info(const RtScene *s, RtSceneInfo *info) {
 int rt_set_stage_timing(RtScene *s, int enabled) {
     if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     s->timing = enabled != 0;
+    return RT_OK;
+}
+
+int rt_set_counting(RtScene *s, int enabled) {
+    if (!s) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    s->counting = enabled != 0;
     return RT_OK;
 }
 

@@ -65,6 +65,9 @@ class Scene:
     def set_stage_timing(self, enabled):
         _abi.check(self._lib.rt_set_stage_timing(self._h, int(bool(enabled))))
 
+    def set_counting(self, enabled):
+        _abi.check(self._lib.rt_set_counting(self._h, int(bool(enabled))))
+
     # ---- <Bvh as Hittable>::hit on a batch --------------------------------
     def closest_hit(self, org_dir, t_min=T_MIN, t_max=T_MAX):
         """org_dir: [n, 6] float32 (origin, direction).  Returns (prim_id[n], t[n], normal[n,3], point[n,3])."""

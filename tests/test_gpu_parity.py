@@ -118,6 +118,18 @@ def test_mesh_hits(pkg, oracle):
     assert (ids >= 2).sum() > 10_000  # plenty of triangle hits
 
 
+def test_degenerate_rays(pkg, oracle):
+    """NaN and zero directions (Ray::new makes them all-NaN), NaN origins, axis-parallel rays on box planes."""
+    d = mixed_scene(pkg)
+    nan = float("nan")
+    rays = np.array([
+        [0, 0, -3, 0, 0, 0], [0, 0, -3, nan, 0, 1], [nan, nan, nan, 0, 0, 1], [nan, 0, 0, 0, 0, 1],
+        [0.5, 0.5, -3, 0, 0, 1], [3.5, 3.5, -3, 0, 0, 1], [3.5, 3, 6, 1, 0, 0], [3, 3.5, 6, 0, -1, 0],
+        [0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 1, 0], [15, 15, 15, -1, -1, -1], [float("inf"), 0, 0, 1, 0, 0],
+    ], dtype=np.float32)
+    check_hits(pkg, oracle, d, rays, expect_hits=False)
+
+
 def test_t_range_bounds(pkg, oracle):
     """Caller-supplied t_min / t_max, including hits exactly at t_max (inclusive for triangles and box entries)."""
     S = pkg.SceneDescription()
