@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtcore.so")
+# RTCORE_LIB selects another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("RTCORE_LIB") or os.path.join(_HERE, "librtcore.so")
 
 RT_OK = 0
 RT_ERR_INVALID_ARGUMENT = -1

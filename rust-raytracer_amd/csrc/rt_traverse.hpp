@@ -216,64 +216,101 @@ struct Stack {
     }
 };
 
-// Bvh::hit for one ray.  COUNT adds node-visit / primitive-test counters.
-template <bool COUNT>
-RT_DEV Best closest_hit(const RtSceneView &sc, const Ray &ray, float t_min, float t_max, Stack &st, uint32_t *visits,
-                        uint32_t *tests) {
+// Bvh::hit for one ray as a resumable state machine, so that a wave can keep its lanes
+// busy with different rays: begin() loads a ray and tests the root box, step() handles one
+// node or one leaf and picks the next entry, and reports when the stack has run empty.
+struct Traversal {
+    Ray ray;
+    F3 inv;
     Best best;
-    best.t = t_max;
-    best.index = -1;
-    best.u = best.v = 0.0f;
-    best.ties = false;
-    const float4 *__restrict__ nodes = (const float4 *)sc.nodes;
-    const float4 *__restrict__ prims = (const float4 *)sc.prims;
+    uint32_t entry;
+};
+
+// Returns false when the result is already known to be a miss (no traversal needed).
+template <bool COUNT>
+RT_DEV bool traversal_begin(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, float t_max,
+                            uint32_t *visits) {
+    tr.best.t = t_max;
+    tr.best.index = -1;
+    tr.best.u = tr.best.v = 0.0f;
+    tr.best.ties = false;
+    st.sp = 0;
+    tr.entry = 0;  // node 0
+    const Ray &ray = tr.ray;
     // A ray whose direction (or origin) is NaN in every component passes every box test of the
     // reference (NaN-ignoring min/max leave t_min <= t_max) and fails every primitive test, so it
     // would walk the whole tree only to miss.  Ray::new turns a zero or NaN direction into such a
     // ray.  The result is known without the walk.
     if ((ray.d.x != ray.d.x && ray.d.y != ray.d.y && ray.d.z != ray.d.z) ||
         (ray.o.x != ray.o.x && ray.o.y != ray.o.y && ray.o.z != ray.o.z))
-        return best;
-    F3 inv = f3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
-    {   // the root's own box (src/tracer/bvh.rs:144-147)
-        F3 t0 = (f3(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2]) - ray.o) * inv;
-        F3 t1 = (f3(sc.root_hi[0], sc.root_hi[1], sc.root_hi[2]) - ray.o) * inv;
-        float tn = fmaxf(max3(f3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z))), t_min);
-        float tf = fminf(min3(f3(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z))), t_max);
-        if (COUNT) (*visits)++;
-        if (!(tn <= tf)) return best;
+        return false;
+    tr.inv = f3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    // the root's own box (src/tracer/bvh.rs:144-147)
+    F3 t0 = (f3(sc.root_lo[0], sc.root_lo[1], sc.root_lo[2]) - ray.o) * tr.inv;
+    F3 t1 = (f3(sc.root_hi[0], sc.root_hi[1], sc.root_hi[2]) - ray.o) * tr.inv;
+    float tn = fmaxf(max3(f3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z))), t_min);
+    float tf = fminf(min3(f3(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z))), t_max);
+    if (COUNT) (*visits)++;
+    return tn <= tf;
+}
+
+// Next entry from the stack; an entry whose box starts beyond the best hit is dropped.
+// Returns true when the stack has run empty: the traversal is finished.
+RT_DEV bool traversal_pop(Traversal &tr, Stack &st) {
+    while (st.sp > 0) {
+        uint32_t w;
+        float t;
+        st.pop(&w, &t);
+        if (t <= tr.best.t) {
+            tr.entry = w;
+            return false;
+        }
     }
-    st.sp = 0;
-    uint32_t entry = 0;  // word of the thing to process next: node 0
-    for (;;) {
-        if (entry & RT_CHILD_LEAF) {
-            int32_t first = (int32_t)(entry & RT_LEAF_FIRST_MASK);
-            int32_t count = (int32_t)((entry >> 28) & 7u) + 1;
-            for (int32_t k = 0; k < count; k++) {
-                if (COUNT) (*tests)++;
-                test_primitive(prims, first + k, ray, t_min, t_max, best);
-            }
-        } else {
-            const float4 *n = nodes + (size_t)entry * RT_NODE_FLOAT4S;
-            float4 lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
-            float4 cwf = n[6];
-            if (COUNT) (*visits)++;
-            uint32_t cw[4] = {__float_as_uint(cwf.x), __float_as_uint(cwf.y), __float_as_uint(cwf.z), __float_as_uint(cwf.w)};
-            float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
-            float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
-            float key[4];
-            const float kInf = __int_as_float(0x7f800000);
+    return true;
+}
+
+// tr.entry is a leaf: tests its primitives, then pops.  Returns true when the traversal is finished.
+template <bool COUNT>
+RT_DEV bool traversal_leaf_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, float t_max,
+                                uint32_t *tests) {
+    const float4 *__restrict__ prims = (const float4 *)sc.prims;
+    const uint32_t entry = tr.entry;
+    int32_t first = (int32_t)(entry & RT_LEAF_FIRST_MASK);
+    int32_t count = (int32_t)((entry >> 28) & 7u) + 1;
+    for (int32_t k = 0; k < count; k++) {
+        if (COUNT) (*tests)++;
+        test_primitive(prims, first + k, tr.ray, t_min, t_max, tr.best);
+    }
+    return traversal_pop(tr, st);
+}
+
+// tr.entry is a node: tests its four child boxes, pushes the far hits, continues with the
+// nearest (or pops).  Returns true when the traversal is finished.
+template <bool COUNT>
+RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
+    const float4 *__restrict__ nodes = (const float4 *)sc.nodes;
+    const Ray &ray = tr.ray;
+    const F3 inv = tr.inv;
+    const float4 *n = nodes + (size_t)tr.entry * RT_NODE_FLOAT4S;
+    float4 lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
+    float4 cwf = n[6];
+    if (COUNT) (*visits)++;
+    uint32_t cw[4] = {__float_as_uint(cwf.x), __float_as_uint(cwf.y), __float_as_uint(cwf.z), __float_as_uint(cwf.w)};
+    float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
+    float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+    float key[4];
+    const float kInf = __int_as_float(0x7f800000);
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                float t0x = (lx[c] - ray.o.x) * inv.x, t1x = (hx[c] - ray.o.x) * inv.x;
-                float t0y = (ly[c] - ray.o.y) * inv.y, t1y = (hy[c] - ray.o.y) * inv.y;
-                float t0z = (lz[c] - ray.o.z) * inv.z, t1z = (hz[c] - ray.o.z) * inv.z;
-                float tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), t_min);
-                float tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), best.t);
-                bool hit = (cw[c] != RT_CHILD_NONE) && (tn <= tf);
-                key[c] = hit ? tn : kInf;
-            }
-            // sort the four (key, word) pairs ascending: (0,1) (2,3) (0,2) (1,3) (1,2)
+    for (int c = 0; c < 4; c++) {
+        float t0x = (lx[c] - ray.o.x) * inv.x, t1x = (hx[c] - ray.o.x) * inv.x;
+        float t0y = (ly[c] - ray.o.y) * inv.y, t1y = (hy[c] - ray.o.y) * inv.y;
+        float t0z = (lz[c] - ray.o.z) * inv.z, t1z = (hz[c] - ray.o.z) * inv.z;
+        float tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), t_min);
+        float tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), tr.best.t);
+        bool hit = (cw[c] != RT_CHILD_NONE) && (tn <= tf);
+        key[c] = hit ? tn : kInf;
+    }
+    // sort the four (key, word) pairs ascending: (0,1) (2,3) (0,2) (1,3) (1,2)
 #define RT_CSWAP(i, j)                    \
     if (key[j] < key[i]) {                \
         float tk = key[i];                \
@@ -283,31 +320,16 @@ RT_DEV Best closest_hit(const RtSceneView &sc, const Ray &ray, float t_min, floa
         cw[i] = cw[j];                    \
         cw[j] = tw;                       \
     }
-            RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+    RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
-            if (key[3] < kInf) st.push(cw[3], key[3]);
-            if (key[2] < kInf) st.push(cw[2], key[2]);
-            if (key[1] < kInf) st.push(cw[1], key[1]);
-            if (key[0] < kInf) {
-                entry = cw[0];
-                continue;
-            }
-        }
-        // next entry from the stack; an entry whose box starts beyond the best hit is dropped
-        bool found = false;
-        while (st.sp > 0) {
-            uint32_t w;
-            float t;
-            st.pop(&w, &t);
-            if (t <= best.t) {
-                entry = w;
-                found = true;
-                break;
-            }
-        }
-        if (!found) break;
+    if (key[3] < kInf) st.push(cw[3], key[3]);
+    if (key[2] < kInf) st.push(cw[2], key[2]);
+    if (key[1] < kInf) st.push(cw[1], key[1]);
+    if (key[0] < kInf) {
+        tr.entry = cw[0];
+        return false;
     }
-    return best;
+    return traversal_pop(tr, st);
 }
 
 }  // namespace rtd

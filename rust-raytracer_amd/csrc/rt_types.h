@@ -48,7 +48,9 @@
 #define RT_PRIM_MAT_SHIFT 4
 
 // LDS entries of the per-lane traversal stack; deeper entries go to an HBM overflow area.
-#define RT_LDS_STACK 16
+#ifndef RT_LDS_STACK
+#define RT_LDS_STACK 12
+#endif
 
 struct RtDevMaterial {  // 32 B
     float albedo[3];

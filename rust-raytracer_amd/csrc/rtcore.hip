@@ -35,6 +35,7 @@ using namespace rtd;
 namespace {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kCountSlots = 1024;  // live-path counts [0, kCountSlots), extend work counters [kCountSlots, 2 kCountSlots)
 constexpr float kTMin = 0.00015f;   // src/render.rs:15
 constexpr float kTMax = 100000.0f;  // src/render.rs:16
 
@@ -56,6 +57,7 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
     if (i == 0) {
         counts[0] = n;
         for (uint32_t k = 1; k < n_counts; k++) counts[k] = 0;
+        for (uint32_t k = 0; k < n_counts; k++) counts[kCountSlots + k] = 0;  // work counters of the extend launches
     }
     if (i >= n) return;
     uint32_t s = i / np, j = i - s * np;
@@ -78,42 +80,130 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
 // hit_a = (t, visit rank, material, primitive id)   rank -1 = miss
 // hit_n = (normal, 0)
 // ---------------------------------------------------------------------------
+// Persistent waves: a wave reserves runs of kRayChunk consecutive ray indices from a global
+// counter and hands them to its lanes; a lane that has finished its ray parks its result, and
+// once kServiceLanes lanes are parked or empty the wave writes the parked results and refills
+// those lanes, so the lanes of a wave work on different rays at different depths instead of
+// idling until the slowest ray of a fixed group of 64 is done.
+#ifndef RT_RAY_CHUNK
+#define RT_RAY_CHUNK 256
+#endif
+#ifndef RT_SERVICE_LANES
+#define RT_SERVICE_LANES 24
+#endif
+#ifndef RT_EXTEND_WAVES
+#define RT_EXTEND_WAVES 6
+#endif
+#ifndef RT_VOTE_ENOUGH
+#define RT_VOTE_ENOUGH 65
+#endif
+#ifndef RT_VOTE_FEW
+#define RT_VOTE_FEW 0
+#endif
+constexpr uint32_t kVoteEnough = RT_VOTE_ENOUGH;
+constexpr uint32_t kVoteFew = RT_VOTE_FEW;
+constexpr uint32_t kRayChunk = RT_RAY_CHUNK;
+constexpr uint32_t kServiceLanes = RT_SERVICE_LANES;
+
 template <bool COUNT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     extend_kernel(RtSceneView sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
                   const uint32_t *__restrict__ count_ptr, uint32_t n_fixed, float t_min, float t_max,
-                  float4 *__restrict__ hit_a, float4 *__restrict__ hit_n, uint2 *ovf,
+                  float4 *__restrict__ hit_a, float4 *__restrict__ hit_n, uint2 *ovf, uint32_t *head,
                   unsigned long long *counters) {
     __shared__ uint32_t s_w[RT_LDS_STACK * kBlock];
     __shared__ float s_t[RT_LDS_STACK * kBlock];
     const uint32_t n = count_ptr ? *count_ptr : n_fixed;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     Stack st;
     st.lds_w = s_w + threadIdx.x;
     st.lds_t = s_t + threadIdx.x;
     st.lds_stride = kBlock;
-    st.ovf = ovf + gtid;
-    st.ovf_stride = stride;
+    st.ovf = ovf + (blockIdx.x * blockDim.x + threadIdx.x);
+    st.ovf_stride = (size_t)gridDim.x * blockDim.x;
     st.sp = 0;
     uint32_t visits = 0, tests = 0;
-    for (uint32_t i = gtid; i < n; i += stride) {
-        float4 o4 = ro[i], d4 = rd[i];
-        Ray ray;
-        ray.o = f3(o4.x, o4.y, o4.z);
-        ray.d = f3(d4.x, d4.y, d4.z);
-        Best best = closest_hit<COUNT>(sc, ray, t_min, t_max, st, &visits, &tests);
-        if (best.index >= 0) {
-            F3 nrm;
-            uint32_t mat;
-            int32_t pid;
-            finish_hit(sc, ray, best, &nrm, &mat, &pid);
-            hit_a[i] = make_float4(best.t, __int_as_float(best.index), __uint_as_float(mat), __int_as_float(pid));
-            hit_n[i] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
-        } else {
-            hit_a[i] = make_float4(0.0f, __int_as_float(-1), 0.0f, __int_as_float(-1));
-            hit_n[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    Traversal tr;
+    int32_t ray_i = -1;     // ray this lane works on, -1 = none
+    bool parked = false;    // traversal finished, result not yet written
+    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: the reserved run of ray indices
+    bool no_more = false;                    // wave-uniform: the global counter ran past n
+
+    for (;;) {
+        const unsigned long long parked_mask = __ballot(parked);
+        const unsigned long long idle_mask = __ballot(parked || ray_i < 0);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (n_idle >= kServiceLanes && (parked_mask != 0ull || !no_more)) {
+            if (parked) {
+                if (tr.best.index >= 0) {
+                    F3 nrm;
+                    uint32_t mat;
+                    int32_t pid;
+                    finish_hit(sc, tr.ray, tr.best, &nrm, &mat, &pid);
+                    hit_a[ray_i] = make_float4(tr.best.t, __int_as_float(tr.best.index), __uint_as_float(mat), __int_as_float(pid));
+                    hit_n[ray_i] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
+                } else {
+                    hit_a[ray_i] = make_float4(0.0f, __int_as_float(-1), 0.0f, __int_as_float(-1));
+                    hit_n[ray_i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                parked = false;
+                ray_i = -1;
+            }
+            // refill; rays that miss the root box (or are NaN) are answered on the spot, so repeat
+            while (!no_more) {
+                const unsigned long long empty_mask = __ballot(ray_i < 0);
+                const uint32_t want = (uint32_t)__popcll(empty_mask);
+                if (want < kServiceLanes) break;
+                if (chunk_next == chunk_end) {
+                    uint32_t b = 0;
+                    if (lane == 0) b = atomicAdd(head, kRayChunk);
+                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                    chunk_next = b < n ? b : n;
+                    chunk_end = (b + kRayChunk) < n ? (b + kRayChunk) : n;
+                    if (b >= n) {
+                        no_more = true;
+                        break;
+                    }
+                }
+                const uint32_t avail = chunk_end - chunk_next;
+                const uint32_t give = want < avail ? want : avail;
+                if (ray_i < 0) {
+                    const uint32_t rank = (uint32_t)__popcll(empty_mask & lanes_below);
+                    if (rank < give) {
+                        const uint32_t i = chunk_next + rank;
+                        float4 o4 = ro[i], d4 = rd[i];
+                        tr.ray.o = f3(o4.x, o4.y, o4.z);
+                        tr.ray.d = f3(d4.x, d4.y, d4.z);
+                        if (traversal_begin<COUNT>(sc, tr, st, t_min, t_max, &visits)) {
+                            ray_i = (int32_t)i;
+                        } else {
+                            hit_a[i] = make_float4(0.0f, __int_as_float(-1), 0.0f, __int_as_float(-1));
+                            hit_n[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        }
+                    }
+                }
+                chunk_next += give;
+            }
         }
+        // One step for part of the wave: lanes at a node and lanes at a leaf need different code,
+        // so each iteration runs only the kind that more lanes are waiting for; the others wait.
+        const bool active = ray_i >= 0 && !parked;
+        const bool at_leaf = active && (tr.entry & RT_CHILD_LEAF) != 0u;
+        const bool at_node = active && !at_leaf;
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+        const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
+        if (n_leaf + n_node == 0u) {
+            if (no_more && __ballot(parked) == 0ull) break;
+            continue;
+        }
+        // A kind runs when it is the majority, when it has enough lanes to be worth its issue
+        // slots anyway, or when so few lanes are active that latency, not issue, is the cost.
+        const bool few = n_leaf + n_node <= kVoteFew;
+        const bool run_leaf = n_leaf >= n_node || n_leaf >= kVoteEnough || few;
+        const bool run_node = n_node > n_leaf || n_node >= kVoteEnough || few;
+        if (run_leaf && at_leaf) parked = traversal_leaf_step<COUNT>(sc, tr, st, t_min, t_max, &tests);
+        if (run_node && at_node) parked = traversal_node_step<COUNT>(sc, tr, st, t_min, &visits);
     }
     if (COUNT) {
         atomicAdd(&counters[0], (unsigned long long)visits);
@@ -121,32 +211,45 @@ __global__ void __launch_bounds__(kBlock)
     }
 }
 
-// Appends the lanes with `alive` to a queue: one atomic per wave, slot = base + rank among the wave's live lanes.
-__device__ __forceinline__ uint32_t wave_compact_slot(bool alive, uint32_t *counter) {
-    unsigned long long mask = __ballot(alive);
-    uint32_t lane = __lane_id();
-    uint32_t total = (uint32_t)__popcll(mask);
-    uint32_t base = 0;
-    if (total) {
-        uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-        if (lane == leader) base = atomicAdd(counter, total);
-        base = (uint32_t)__shfl((int)base, (int)leader);
+// Appends the lanes with `alive` to a queue.  One atomic per block: each wave counts its live
+// lanes with a ballot, wave leaders leave the counts in LDS, one thread reserves the block's run
+// and every lane takes base + (live lanes of earlier waves) + (live lanes below it in its wave).
+// A single global counter sustains only about 90 atomics per microsecond, so per-wave atomics
+// would cap a 4K pass at that rate.  Must be called by every thread of the block.
+constexpr int kShadeBlock = 1024;
+__device__ __forceinline__ uint32_t block_compact_slot(bool alive, uint32_t *counter, uint32_t *s_counts) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const unsigned long long mask = __ballot(alive);
+    if (lane == 0) s_counts[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < n_waves; w++) {
+            uint32_t c = s_counts[w];
+            s_counts[w] = total;
+            total += c;
+        }
+        s_counts[n_waves] = total ? atomicAdd(counter, total) : 0u;
     }
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();
+    const uint32_t dst = s_counts[n_waves] + s_counts[wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads();  // s_counts is reused by the next call
+    return dst;
 }
 
 // ---------------------------------------------------------------------------
 // shade: the body of ray_color's loop (src/render.rs:62-81) for bounce `bounce`
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kShadeBlock)
     shade_kernel(RtSceneView sc, PathState in, const float4 *__restrict__ hit_a, const float4 *__restrict__ hit_n,
                  const uint32_t *__restrict__ count_in, PathState out, uint32_t *count_out, float4 *__restrict__ rad,
                  uint32_t bounce, uint32_t depth, float light_clamp) {
+    __shared__ uint32_t s_counts[kShadeBlock / 64 + 1];
     const uint32_t n = *count_in;
     const uint32_t stride = gridDim.x * blockDim.x;
     const RtDevMaterial *mats = (const RtDevMaterial *)sc.materials;
-    // every lane of a wave runs the same number of iterations so the ballot sees whole waves
-    const uint32_t n_round = (n + 63u) & ~63u;
+    // every thread of a block runs the same number of iterations: the compaction has barriers
+    const uint32_t n_round = (n + (uint32_t)kShadeBlock - 1u) / (uint32_t)kShadeBlock * (uint32_t)kShadeBlock;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         bool alive = false;
         float4 o4, d4, th4;
@@ -190,7 +293,7 @@ __global__ void __launch_bounds__(kBlock)
             }
             if (!alive) rad[slot] = make_float4(result.x, result.y, result.z, 0.0f);
         }
-        uint32_t dst = wave_compact_slot(alive, count_out);
+        uint32_t dst = block_compact_slot(alive, count_out, s_counts);
         if (alive) {
             out.o[dst] = make_float4(new_o.x, new_o.y, new_o.z, o4.w);
             out.d[dst] = make_float4(new_d.x, new_d.y, new_d.z, 0.0f);
@@ -393,7 +496,7 @@ int ensure_work(RtScene *s, uint64_t paths) {
     if ((rc = s->hit_a.ensure(paths * 16))) return rc;
     if ((rc = s->hit_n.ensure(paths * 16))) return rc;
     if ((rc = s->rad.ensure(paths * 16))) return rc;
-    if ((rc = s->counts.ensure(4096))) return rc;
+    if ((rc = s->counts.ensure(2 * kCountSlots * sizeof(uint32_t)))) return rc;
     if (!s->totals.p) {
         if ((rc = s->totals.ensure(64))) return rc;
         RT_HIP(hipMemset(s->totals.p, 0, 64));
@@ -402,7 +505,12 @@ int ensure_work(RtScene *s, uint64_t paths) {
         if ((rc = s->counters.ensure(64))) return rc;
         RT_HIP(hipMemset(s->counters.p, 0, 64));
     }
-    s->extend_blocks = (uint32_t)s->n_cus * 8u;
+    {   // persistent waves: launch what is resident at once
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, extend_kernel<false>, kBlock, 0) != hipSuccess || per_cu < 1)
+            per_cu = 4;
+        s->extend_blocks = (uint32_t)s->n_cus * (uint32_t)per_cu;
+    }
     uint32_t deep = s->view.max_stack > RT_LDS_STACK ? s->view.max_stack - RT_LDS_STACK : 0;
     if (deep) {
         if ((rc = s->ovf.ensure((size_t)deep * s->extend_blocks * kBlock * sizeof(uint2)))) return rc;
@@ -443,18 +551,19 @@ struct StageTimer {
 
 uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
+// `head` is the work counter of this launch; it must be zero when the kernel starts.
 int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4 *rd, const uint32_t *count_ptr,
-                  uint32_t n_upper, float t_min, float t_max, bool counted) {
+                  uint32_t n_upper, float t_min, float t_max, bool counted, uint32_t *head) {
     if (n_upper == 0) return RT_OK;
     uint32_t blocks = std::min(blocks_for(n_upper), s->extend_blocks);
     StageTimer tm(s, stream, 0);
     if (counted)
         hipLaunchKernelGGL(extend_kernel<true>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
-                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (float4 *)s->hit_n.p, (uint2 *)s->ovf.p,
+                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (float4 *)s->hit_n.p, (uint2 *)s->ovf.p, head,
                            (unsigned long long *)s->counters.p);
     else
         hipLaunchKernelGGL(extend_kernel<false>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
-                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (float4 *)s->hit_n.p, (uint2 *)s->ovf.p,
+                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (float4 *)s->hit_n.p, (uint2 *)s->ovf.p, head,
                            (unsigned long long *)s->counters.p);
     RT_HIP(hipGetLastError());
     return RT_OK;
@@ -490,7 +599,7 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
     const bool first_hit_only = preview || p->mode != RT_MODE_IMAGE;
     const uint32_t depth = first_hit_only ? 1u : p->max_bounce;
     const uint32_t n_counts = depth + 2;
-    if (n_counts > 1024) return fail(RT_ERR_INVALID_ARGUMENT, "max_bounce too large");
+    if (n_counts > kCountSlots) return fail(RT_ERR_INVALID_ARGUMENT, "max_bounce too large");
     uint32_t *counts = (uint32_t *)s->counts.p;
     PathState st[2];
     for (int k = 0; k < 2; k++) st[k] = PathState{(float4 *)s->st_o[k].p, (float4 *)s->st_d[k].p, (float4 *)s->st_thr[k].p};
@@ -511,7 +620,9 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
         }
         int cur = 0;
         for (uint32_t b = 0; b < depth; b++) {
-            if ((rc = launch_extend(s, stream, st[cur].o, st[cur].d, counts + b, n, kTMin, kTMax, s->counting))) return rc;
+            if ((rc = launch_extend(s, stream, st[cur].o, st[cur].d, counts + b, n, kTMin, kTMax, s->counting,
+                                    counts + kCountSlots + b)))
+                return rc;
             StageTimer tm(s, stream, 1);
             uint32_t blocks = std::min(blocks_for(n), (uint32_t)s->n_cus * 16u);
             if (first_hit_only) {
@@ -519,7 +630,8 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
                                    (const float4 *)s->hit_a.p, (const float4 *)s->hit_n.p, counts + b, rad,
                                    preview && p->mode == RT_MODE_IMAGE ? (int)RT_MODE_IMAGE : (int)p->mode);
             } else {
-                hipLaunchKernelGGL(shade_kernel, dim3(blocks), dim3(kBlock), 0, stream, s->view, st[cur],
+                uint32_t sblocks = std::min((n + kShadeBlock - 1) / kShadeBlock, (uint32_t)s->n_cus * 4u);
+                hipLaunchKernelGGL(shade_kernel, dim3(sblocks), dim3(kShadeBlock), 0, stream, s->view, st[cur],
                                    (const float4 *)s->hit_a.p, (const float4 *)s->hit_n.p, counts + b, st[cur ^ 1],
                                    counts + b + 1, rad, b, depth, p->light_clamp);
             }
@@ -741,7 +853,9 @@ static int closest_hit_device(RtScene *s, const float *d_org_dir, float t_min, f
             StageTimer tm(s, stream, 2);
             hipLaunchKernelGGL(pack_rays_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream, d_org_dir + off * 6, m, ro, rd);
         }
-        if ((rc = launch_extend(s, stream, ro, rd, nullptr, m, t_min, t_max, counted))) return rc;
+        uint32_t *head = (uint32_t *)s->counts.p + 2 * kCountSlots - 1;
+        RT_HIP(hipMemsetAsync(head, 0, sizeof(uint32_t), stream));
+        if ((rc = launch_extend(s, stream, ro, rd, nullptr, m, t_min, t_max, counted, head))) return rc;
         {
             StageTimer tm(s, stream, 2);
             hipLaunchKernelGGL(unpack_hits_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream,
