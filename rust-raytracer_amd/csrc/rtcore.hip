@@ -77,8 +77,8 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
 
 // ---------------------------------------------------------------------------
 // extend: Bvh::hit for every live path (src/tracer/bvh.rs:143)
-// hit_a = (t, visit rank, material, primitive id)   rank -1 = miss
-// hit_n = (normal, 0)
+// hit = (t, visit rank, u, v)   rank -1 = miss; the consumer completes the HitRecord (normal,
+// material, primitive id) with finish_hit, where all lanes of a wave are busy
 // ---------------------------------------------------------------------------
 // Persistent waves: a wave reserves runs of kRayChunk consecutive ray indices from a global
 // counter and hands them to its lanes; a lane that has finished its ray parks its result, and
@@ -109,8 +109,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     extend_kernel(RtSceneView sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
                   const uint32_t *__restrict__ count_ptr, uint32_t n_fixed, float t_min, float t_max,
-                  float4 *__restrict__ hit_a, float4 *__restrict__ hit_n, uint2 *ovf, uint32_t *head,
-                  unsigned long long *counters) {
+                  float4 *__restrict__ hit, uint2 *ovf, uint32_t *head, unsigned long long *counters) {
     __shared__ uint32_t s_w[RT_LDS_STACK * kBlock];
     __shared__ float s_t[RT_LDS_STACK * kBlock];
     const uint32_t n = count_ptr ? *count_ptr : n_fixed;
@@ -136,17 +135,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
         if (n_idle >= kServiceLanes && (parked_mask != 0ull || !no_more)) {
             if (parked) {
-                if (tr.best.index >= 0) {
-                    F3 nrm;
-                    uint32_t mat;
-                    int32_t pid;
-                    finish_hit(sc, tr.ray, tr.best, &nrm, &mat, &pid);
-                    hit_a[ray_i] = make_float4(tr.best.t, __int_as_float(tr.best.index), __uint_as_float(mat), __int_as_float(pid));
-                    hit_n[ray_i] = make_float4(nrm.x, nrm.y, nrm.z, 0.0f);
-                } else {
-                    hit_a[ray_i] = make_float4(0.0f, __int_as_float(-1), 0.0f, __int_as_float(-1));
-                    hit_n[ray_i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
+                hit[ray_i] = make_float4(tr.best.t, __int_as_float(tr.best.index), tr.best.u, tr.best.v);
                 parked = false;
                 ray_i = -1;
             }
@@ -178,8 +167,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
                         if (traversal_begin<COUNT>(sc, tr, st, t_min, t_max, &visits)) {
                             ray_i = (int32_t)i;
                         } else {
-                            hit_a[i] = make_float4(0.0f, __int_as_float(-1), 0.0f, __int_as_float(-1));
-                            hit_n[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            hit[i] = make_float4(0.0f, __int_as_float(-1), 0.0f, 0.0f);
                         }
                     }
                 }
@@ -241,7 +229,7 @@ __device__ __forceinline__ uint32_t block_compact_slot(bool alive, uint32_t *cou
 // shade: the body of ray_color's loop (src/render.rs:62-81) for bounce `bounce`
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kShadeBlock)
-    shade_kernel(RtSceneView sc, PathState in, const float4 *__restrict__ hit_a, const float4 *__restrict__ hit_n,
+    shade_kernel(RtSceneView sc, PathState in, const float4 *__restrict__ hit_a,
                  const uint32_t *__restrict__ count_in, PathState out, uint32_t *count_out, float4 *__restrict__ rad,
                  uint32_t bounce, uint32_t depth, float light_clamp) {
     __shared__ uint32_t s_counts[kShadeBlock / 64 + 1];
@@ -267,10 +255,14 @@ __global__ void __launch_bounds__(kShadeBlock)
             thr = f3(th4.x, th4.y, th4.z);
             F3 result;
             if (__float_as_int(ha.y) >= 0) {
-                float4 hn = hit_n[i];
-                RtDevMaterial m = mats[__float_as_uint(ha.z)];
+                Best best{ha.x, __float_as_int(ha.y), ha.z, ha.w, false};
+                F3 nrm;
+                uint32_t mat;
+                int32_t pid;
+                finish_hit(sc, ray, best, &nrm, &mat, &pid);
+                RtDevMaterial m = mats[mat];
                 F3 sdir;
-                F3 att = scatter(m, ray, ha.x, f3(hn.x, hn.y, hn.z), key, bounce, &sdir);
+                F3 att = scatter(m, ray, ha.x, nrm, key, bounce, &sdir);
                 if (max3(att) <= 1.0f) {
                     thr = thr * att;
                     if (max3(thr) < draw(key, bounce, DIM_RR)) {
@@ -305,7 +297,7 @@ __global__ void __launch_bounds__(kShadeBlock)
 // normals_only / colors_only / no_bounce (src/render.rs:107-138): every path ends after its first hit
 __global__ void __launch_bounds__(kBlock)
     shade_first_hit_kernel(RtSceneView sc, PathState in, const float4 *__restrict__ hit_a,
-                           const float4 *__restrict__ hit_n, const uint32_t *__restrict__ count_in,
+                           const uint32_t *__restrict__ count_in,
                            float4 *__restrict__ rad, int mode) {
     const uint32_t n = *count_in;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -319,9 +311,12 @@ __global__ void __launch_bounds__(kBlock)
         ray.d = f3(d4.x, d4.y, d4.z);
         F3 result;
         if (__float_as_int(ha.y) >= 0) {
-            float4 hn = hit_n[i];
-            F3 nrm = f3(hn.x, hn.y, hn.z);
-            RtDevMaterial m = mats[__float_as_uint(ha.z)];
+            Best best{ha.x, __float_as_int(ha.y), ha.z, ha.w, false};
+            F3 nrm;
+            uint32_t mat;
+            int32_t pid;
+            finish_hit(sc, ray, best, &nrm, &mat, &pid);
+            RtDevMaterial m = mats[mat];
             if (mode == RT_MODE_NORMALS) {
                 result = (nrm + f3(1.0f, 1.0f, 1.0f)) * 0.5f;
             } else if (mode == RT_MODE_COLORS) {
@@ -396,23 +391,29 @@ __global__ void __launch_bounds__(kBlock)
     rd[i] = make_float4(d.x, d.y, d.z, 0.0f);
 }
 __global__ void __launch_bounds__(kBlock)
-    unpack_hits_kernel(const float4 *__restrict__ hit_a, const float4 *__restrict__ hit_n,
-                       const float4 *__restrict__ ro, const float4 *__restrict__ rd, uint32_t n, int32_t *prim_id,
-                       float *t, float *normal, float *point) {
+    unpack_hits_kernel(RtSceneView sc, const float4 *__restrict__ hit_a, const float4 *__restrict__ ro,
+                       const float4 *__restrict__ rd, uint32_t n, int32_t *prim_id, float *t, float *normal,
+                       float *point) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float4 ha = hit_a[i], hn = hit_n[i];
+    float4 ha = hit_a[i], o4 = ro[i], d4 = rd[i];
     bool ok = __float_as_int(ha.y) >= 0;
-    if (prim_id) prim_id[i] = __float_as_int(ha.w);
+    Ray ray;
+    ray.o = f3(o4.x, o4.y, o4.z);
+    ray.d = f3(d4.x, d4.y, d4.z);
+    F3 nrm = f3(0.0f, 0.0f, 0.0f);
+    uint32_t mat = 0;
+    int32_t pid = -1;
+    if (ok) {
+        Best best{ha.x, __float_as_int(ha.y), ha.z, ha.w, false};
+        finish_hit(sc, ray, best, &nrm, &mat, &pid);
+    }
+    if (prim_id) prim_id[i] = pid;
     if (t) t[i] = ok ? ha.x : 0.0f;
     if (normal) {
-        normal[(size_t)i * 3] = hn.x, normal[(size_t)i * 3 + 1] = hn.y, normal[(size_t)i * 3 + 2] = hn.z;
+        normal[(size_t)i * 3] = nrm.x, normal[(size_t)i * 3 + 1] = nrm.y, normal[(size_t)i * 3 + 2] = nrm.z;
     }
     if (point) {
-        float4 o4 = ro[i], d4 = rd[i];
-        Ray ray;
-        ray.o = f3(o4.x, o4.y, o4.z);
-        ray.d = f3(d4.x, d4.y, d4.z);
         F3 p = ok ? ray_at(ray, ha.x) : f3(0.0f, 0.0f, 0.0f);
         point[(size_t)i * 3] = p.x, point[(size_t)i * 3 + 1] = p.y, point[(size_t)i * 3 + 2] = p.z;
     }
@@ -494,7 +495,6 @@ int ensure_work(RtScene *s, uint64_t paths) {
         if ((rc = s->st_thr[k].ensure(paths * 16))) return rc;
     }
     if ((rc = s->hit_a.ensure(paths * 16))) return rc;
-    if ((rc = s->hit_n.ensure(paths * 16))) return rc;
     if ((rc = s->rad.ensure(paths * 16))) return rc;
     if ((rc = s->counts.ensure(2 * kCountSlots * sizeof(uint32_t)))) return rc;
     if (!s->totals.p) {
@@ -559,11 +559,11 @@ int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4
     StageTimer tm(s, stream, 0);
     if (counted)
         hipLaunchKernelGGL(extend_kernel<true>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
-                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (float4 *)s->hit_n.p, (uint2 *)s->ovf.p, head,
+                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (uint2 *)s->ovf.p, head,
                            (unsigned long long *)s->counters.p);
     else
         hipLaunchKernelGGL(extend_kernel<false>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
-                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (float4 *)s->hit_n.p, (uint2 *)s->ovf.p, head,
+                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (uint2 *)s->ovf.p, head,
                            (unsigned long long *)s->counters.p);
     RT_HIP(hipGetLastError());
     return RT_OK;
@@ -627,12 +627,12 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
             uint32_t blocks = std::min(blocks_for(n), (uint32_t)s->n_cus * 16u);
             if (first_hit_only) {
                 hipLaunchKernelGGL(shade_first_hit_kernel, dim3(blocks), dim3(kBlock), 0, stream, s->view, st[cur],
-                                   (const float4 *)s->hit_a.p, (const float4 *)s->hit_n.p, counts + b, rad,
+                                   (const float4 *)s->hit_a.p, counts + b, rad,
                                    preview && p->mode == RT_MODE_IMAGE ? (int)RT_MODE_IMAGE : (int)p->mode);
             } else {
                 uint32_t sblocks = std::min((n + kShadeBlock - 1) / kShadeBlock, (uint32_t)s->n_cus * 4u);
                 hipLaunchKernelGGL(shade_kernel, dim3(sblocks), dim3(kShadeBlock), 0, stream, s->view, st[cur],
-                                   (const float4 *)s->hit_a.p, (const float4 *)s->hit_n.p, counts + b, st[cur ^ 1],
+                                   (const float4 *)s->hit_a.p, counts + b, st[cur ^ 1],
                                    counts + b + 1, rad, b, depth, p->light_clamp);
             }
             cur ^= 1;
@@ -859,7 +859,7 @@ static int closest_hit_device(RtScene *s, const float *d_org_dir, float t_min, f
         {
             StageTimer tm(s, stream, 2);
             hipLaunchKernelGGL(unpack_hits_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream,
-                               (const float4 *)s->hit_a.p, (const float4 *)s->hit_n.p, ro, rd, m,
+                               s->view, (const float4 *)s->hit_a.p, ro, rd, m,
                                d_id ? d_id + off : nullptr, d_t ? d_t + off : nullptr,
                                d_normal ? d_normal + off * 3 : nullptr, d_point ? d_point + off * 3 : nullptr);
         }
