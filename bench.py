@@ -42,6 +42,9 @@ def build_workload(pkg, args):
     elif args.workload == "cornell":
         desc = pkg.scenes.cornell()
         name = "Cornell box (values of scene/example/cornell.ron)"
+    elif args.workload == "teaset":
+        desc = pkg.scenes.teaset()
+        name = "Newell tea set (8 OBJ models, 17,228 triangles, glass + ceramic + steel) under a procedural HDR sky"
     elif args.workload == "rtiow":
         desc = pkg.scenes.rtiow(seed=1)
         name = "procedural RTIOW spheres scene (seeded)"

@@ -174,3 +174,57 @@ class SceneDescription:
             d.env.height, d.env.width = self.env.shape[0], self.env.shape[1]
         self._keep = [mats, objs, meshes]
         return d
+
+
+def to_ron(desc, mesh_paths=None):
+    """Serialises a SceneDescription in the reference's scene-file schema (src/io.rs:24-94).
+    Mesh objects need `mesh_paths[i]` = OBJ path of mesh i (one path per tobj model is not expressible, so
+    consecutive objects sharing a path are written once)."""
+    names = {i: n for n, i in desc.material_names.items()}
+
+    def mname(i):
+        return names.get(i, "m%d" % i)
+
+    def t3(v):
+        return "(%s)" % ", ".join(repr(float(np.float32(x))) for x in v)
+
+    cam = desc.camera
+    out = ["Scene(", "    hdr: None,",
+           "    camera: (position: %s, lookat: %s, fov: %r, focus_dist: %r, apeture: %r)," % (
+               t3(cam["eye"]), t3(cam["lookat"]), float(cam["fov"]), float(cam["focus_dist"]), float(cam["aperture"])),
+           "    materials: {"]
+    for i, (t, alb, p0, p1) in enumerate(desc.materials):
+        if t == _abi.RT_MAT_LAMBERTIAN:
+            body = "Lambertian(%s)" % t3(alb)
+        elif t == _abi.RT_MAT_GLOSSY:
+            body = "Glossy(%s, Some(%r), Some(%r))" % (t3(alb), p0, p1)
+        elif t == _abi.RT_MAT_METAL:
+            body = "Metal(%s, Some(%r))" % (t3(alb), p0)
+        else:
+            body = "Dielectric(%s, Some(%r), Some(%r))" % (t3(alb), p0, p1)
+        out.append('        "%s": %s,' % (mname(i), body))
+    out += ["    },", "    objects: ["]
+    last_mesh_path = None
+    for k, o in enumerate(desc.objects):
+        t = o["type"]
+        if t == _abi.RT_OBJ_SPHERE:
+            shape = "Sphere(%s, Some(%r))" % (t3(o["a"]), float(np.float32(o["b"][0])))
+        elif t == _abi.RT_OBJ_ABOX:
+            shape = "AxisBox(%s, Some(%s))" % (t3(o["a"]), t3(o["b"]))
+        elif t == _abi.RT_OBJ_CUBE:
+            shape = "Box(%s, Some(%s), Some(%s))" % (t3(o["a"]), t3(o["b"]), t3(o["c"]))
+        elif t == _abi.RT_OBJ_TRIANGLE:
+            v = o["tri_v"]
+            shape = "Triangle((%s))" % ", ".join("[%s]" % ", ".join(repr(float(x)) for x in v[3 * i:3 * i + 3]) for i in range(3))
+        else:
+            m = desc.meshes[o["mesh"]]
+            path = mesh_paths[o["mesh"]]
+            if path == last_mesh_path:
+                continue
+            last_mesh_path = path
+            rot = [float(r) / math.pi for r in m["rotation"]]
+            shape = 'Mesh("%s", Some(%s), Some(%s), Some(%s), %s)' % (
+                path, t3(m["translation"]), t3(m["scale"]), t3(rot), "true" if m["cull"] else "false")
+        out.append('        (name: Some("object %d"), shape: %s, material: "%s"),' % (k, shape, mname(o["material"])))
+    out += ["    ],", ")"]
+    return "\n".join(out) + "\n"

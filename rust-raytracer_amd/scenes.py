@@ -192,3 +192,35 @@ def sky_map(width=2048, height=1024, sun_dir=(0.4, 0.7, -0.6), sun_radiance=50.0
     img = np.where((dy < 0)[..., None], ground, sky)
     img = img + (cosang > math.cos(math.radians(3.0)))[..., None] * sun_radiance
     return img.astype(np.float32)
+
+
+def teaset(fixture=None, env_size=(2048, 1024)):
+    """The reference's tea-set scene (values of scene/example/teapot.ron): four OBJ files = eight tobj models
+    (17,228 triangles) on a table, ceramic / glass / steel, lit by an environment map.  The meshes come from
+    tests/golden/teaset.npz (made by tools/make_teaset_fixture.py from the reference's OBJ data); the HDR the scene
+    names is not distributable, so a procedural sky stands in (sky_map)."""
+    import os
+
+    if fixture is None:
+        fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "teaset.npz")
+    z = np.load(fixture)
+    s = SceneDescription()
+    s.set_camera(eye=(-0.5, 1.3, -3.0), lookat=(0.2, 1.0, 0.0), fov=50.0, focus_dist=3.0, aperture=0.1)
+    s.add_material(metal((0.58, 0.56, 0.57), 0.1), "stainless steel")
+    s.add_material(glossy((0.85, 0.82, 0.77), 0.95, 0.005), "ceramic")
+    s.add_material(glossy((0.51, 0.29, 0.14), 0.25, 0.9), "wood")
+    s.add_material(dielectric((0.6, 0.1, 0.25), 1.52, 0.025), "glass")
+    s.add_axis_box((0.0, -0.005, 0.0), (6.5, 0.01, 5.0), "wood")
+
+    def add(name, material, translation, scale, rotation, cull):
+        for i in range(int(z[name + "_count"])):
+            s.add_mesh(z["%s_%d_positions" % (name, i)], z["%s_%d_normals" % (name, i)], z["%s_%d_indices" % (name, i)],
+                       material=material, translation=translation, scale=scale, rotation=rotation, cull_backface=cull)
+
+    add("teapot", "ceramic", (-1.7, 1.25, 1.7), (0.5, 0.5, 0.5), (-0.2, 0.25, 0.0), False)
+    add("teacup", "ceramic", (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), (0.0, -0.7, 0.0), True)
+    add("cup", "glass", (1.5, 0.6, -0.5), (0.05, 0.05, 0.05), (0.0, 0.0, 0.0), False)
+    add("spoon", "stainless steel", (-0.9, 0.085, 0.3), (1.5, 1.5, 1.5), (0.025, -0.8, 0.0), True)
+    if env_size:
+        s.set_environment(sky_map(env_size[0], env_size[1]))
+    return s

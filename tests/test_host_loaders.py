@@ -1,0 +1,129 @@
+"""Host-side loaders: the RON / OBJ readers of the C++ host (through `rtrender --validate`, no GPU),
+the Python OBJ twin, and the committed tea-set fixture."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTRENDER = os.path.join(ROOT, "rust-raytracer_amd", "rtrender")
+REF = "/root/reference"
+
+
+def validate(args):
+    out = subprocess.check_output([RTRENDER, "--validate"] + args, stderr=subprocess.STDOUT).decode()
+    m = re.search(r"objects (\d+) materials (\d+) meshes (\d+) primitives (\d+) triangles (\d+)", out)
+    cam = re.search(r"camera eye (\S+) (\S+) (\S+) lookat (\S+) (\S+) (\S+) fov (\S+) focus (\S+) aperture (\S+)", out)
+    return [int(x) for x in m.groups()], [float(x) for x in cam.groups()]
+
+
+OWN_SCENE = """
+// every construct of the scene schema, in this project's own words
+Scene(
+    hdr: None,
+    camera: (position: (1.0, 2.0, -3.0), lookat: (0.0, 0.5, 0.0), fov: 45.0, focus_dist: 4.0, apeture: 0.05),
+    materials: {
+        "matte": Lambertian((0.5, 0.4, 0.3)),
+        "shiny": Glossy((0.9, 0.9, 0.9), Some(0.8), None),
+        "steel": Metal((0.6, 0.6, 0.6), None),
+        "glass": Dielectric((0.1, 0.2, 0.3), None, Some(0.01)),
+    },
+    objects: [
+        (name: Some("ball"), shape: Sphere((0.0, 1.0, 0.0), None), material: "glass"),
+        (name: None, shape: Sphere((2.0, 0.5, 0.0), Some(0.5)), material: "steel"),
+        (name: Some("tri"), shape: Triangle(([0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0])), material: "matte"),
+        (name: Some("crate"), shape: Box((-2.0, 0.5, 0.0), Some((1.0, 1.0, 1.0)), Some((0.0, 0.25, 0.0))), material: "shiny"),
+        (name: Some("floor"), shape: AxisBox((0.0, -0.05, 0.0), Some((20.0, 0.1, 20.0))), material: "matte",), /* trailing comma */
+        (name: Some("mesh"), shape: Mesh("%s", Some((0.0, 0.0, 2.0)), None, Some((0.0, 0.5, 0.0)), true), material: "steel"),
+    ],
+)
+"""
+
+OWN_OBJ = """# two groups, a quad and a pentagon, v/vt/vn and v//vn corners, negative indices
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vn 0 0 1
+vt 0 0
+g first group
+f 1/1/1 2/1/1 3/1/1 4/1/1
+g second
+v 2 0 0
+v 3 0 0
+v 3.5 1 0
+v 2.5 2 0
+v 1.5 1 0
+f -5//1 -4//1 -3//1 -2//1 -1//1
+l 1 2
+p 1
+"""
+
+
+def test_ron_and_obj_readers_on_own_files(tmp_path, pkg):
+    obj = tmp_path / "own.obj"
+    obj.write_text(OWN_OBJ)
+    scene = tmp_path / "own.ron"
+    scene.write_text(OWN_SCENE % str(obj))
+    counts, cam = validate([str(scene)])
+    # 5 simple objects + 2 tobj models; 5 + (2 + 3) triangles
+    assert counts == [7, 4, 2, 10, 6]
+    assert cam == [1.0, 2.0, -3.0, 0.0, 0.5, 0.0, 45.0, 4.0, 0.05]
+    models = pkg.objio.load(str(obj))
+    assert [m["name"] for m in models] == ["first group", "second"]
+    assert [len(m["indices"]) for m in models] == [2, 3]
+    assert models[0]["indices"].tolist() == [[0, 1, 2], [0, 2, 3]]  # fan triangulation
+    assert models[1]["indices"].tolist() == [[0, 1, 2], [0, 2, 3], [0, 3, 4]]
+    assert np.allclose(models[1]["positions"][0], [2, 0, 0])
+
+
+def test_scene_errors_are_reported(tmp_path):
+    bad = tmp_path / "bad.ron"
+    bad.write_text('Scene(hdr: None, camera: (position: (0,0,0), lookat: (0,0,1), fov: 40.0, focus_dist: 1.0, apeture: 0.0), materials: {}, objects: [(name: None, shape: Sphere((0,0,0), None), material: "nope")])')
+    r = subprocess.run([RTRENDER, "--validate", str(bad)], capture_output=True)
+    assert r.returncode == 1 and b"unknown material" in r.stderr
+    bad.write_text("Scene(hdr: None, camera: (")
+    r = subprocess.run([RTRENDER, "--validate", str(bad)], capture_output=True)
+    assert r.returncode == 1 and b"RON parse error" in r.stderr
+
+
+def test_default_scene_matches_the_reference_recipe():
+    counts, cam = validate([])
+    assert counts[2] == 0 and 400 < counts[0] <= 488  # ground + up to 484 small spheres + 3 big ones
+    assert cam == [13.0, 2.0, 3.0, 0.0, 0.0, 0.0, 20.0, 10.0, 0.1]
+
+
+def test_teaset_fixture(pkg):
+    z = np.load(os.path.join(ROOT, "tests", "golden", "teaset.npz"))
+    tri = {n: sum(len(z["%s_%d_indices" % (n, i)]) for i in range(int(z[n + "_count"]))) for n in ("teapot", "teacup", "cup", "spoon")}
+    assert tri == {"teapot": 6320, "teacup": 5200, "cup": 2624, "spoon": 3084}
+    assert [int(z[n + "_count"]) for n in ("teapot", "teacup", "cup", "spoon")] == [4, 2, 1, 1]
+    S = pkg.scenes.teaset(env_size=None)
+    assert S.num_primitives() == 17229
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only mounted in the build container")
+def test_reference_scene_files_parse(tmp_path, pkg):
+    counts, cam = validate([os.path.join(REF, "scene/example/cornell.ron")])
+    assert counts == [9, 5, 0, 9, 0] and cam[:3] == [0.0, 0.0, -22.0]
+    counts, _ = validate([os.path.join(REF, "scene/example/test.ron")])
+    assert counts[0] == 4
+    counts, _ = validate([os.path.join(REF, "scene/example/box_scene.ron")])
+    assert counts[0] == 7
+    # teapot.ron names its meshes by Windows absolute paths: point them at the mounted copies
+    text = open(os.path.join(REF, "scene/example/teapot.ron")).read()
+    text = text.replace("C:\\\\Git_Projects\\\\Rust-Raytracer\\\\scene\\\\models\\\\newell_teaset\\\\", REF + "/scene/models/newell_teaset/")
+    local = tmp_path / "teapot_local.ron"
+    local.write_text(text)
+    counts, cam = validate([str(local)])
+    assert counts == [9, 7, 8, 17229, 17228]
+    # the C++ reader, the Python twin and the committed fixture agree
+    z = np.load(os.path.join(ROOT, "tests", "golden", "teaset.npz"))
+    for name in ("teapot", "teacup", "cup", "spoon"):
+        models = pkg.objio.load(os.path.join(REF, "scene/models/newell_teaset", name + ".obj"))
+        assert len(models) == int(z[name + "_count"])
+        for i, m in enumerate(models):
+            assert np.array_equal(m["indices"], z["%s_%d_indices" % (name, i)])
+            assert np.array_equal(m["positions"], z["%s_%d_positions" % (name, i)])
