@@ -78,15 +78,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the core has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; RT_BENCH_BACKEND=gloo lets several ranks share one card to rehearse the N > 1 control flow
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     import __graft_entry__ as ge
 
     pkg = ge.load_package()
     lib = pkg.load()
-    pkg._abi.check(lib.rt_init(local_rank))
+    pkg._abi.check(lib.rt_init(device_index))
 
     t0 = time.time()
     desc, wl_name = build_workload(pkg, args)
