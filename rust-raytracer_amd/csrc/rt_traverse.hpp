@@ -48,8 +48,8 @@ RT_DEV void consider(Best &b, float t, bool ties, int32_t index, float u, float 
 }
 
 // ABox::hit without the normal (src/tracer/cube.rs:42-56): candidate t and whether it is the entry face
-RT_DEV bool abox_candidate(F3 lo, F3 hi, const Ray &ray, float t_min, float t_max, float *t_out, bool *entry) {
-    F3 inv = f3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+// `inv` is 1/ray.d per component (ABox::hit computes it itself, src/tracer/cube.rs:43; the value is the same)
+RT_DEV bool abox_candidate(F3 lo, F3 hi, const Ray &ray, F3 inv, float t_min, float t_max, float *t_out, bool *entry) {
     F3 t0 = (lo - ray.o) * inv;
     F3 t1 = (hi - ray.o) * inv;
     float t_near = fmaxf(max3(f3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z))), t_min);
@@ -97,8 +97,8 @@ RT_DEV Ray cube_local_ray(F3 center, Rotor rot, const Ray &ray) {
 }
 
 // Tests the primitive at `index` and offers its candidate to `best`.  t_max is the ray's own bound.
-RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, const Ray &ray, float t_min, float t_max,
-                           Best &best) {
+RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, const Ray &ray, F3 inv, float t_min,
+                           float t_max, Best &best) {
     const float4 *r = prims + (size_t)index * RT_PRIM_FLOAT4S;
     float4 r0 = r[0], r1 = r[1], r2 = r[2];
     uint32_t meta = __float_as_uint(r2.z);
@@ -141,14 +141,15 @@ RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, cons
         F3 lo = f3(r0.x, r0.y, r0.z), hi = f3(r0.w, r1.x, r1.y);
         float t;
         bool entry;
-        if (abox_candidate(lo, hi, ray, t_min, t_max, &t, &entry)) consider(best, t, entry, index, 0.0f, 0.0f);
+        if (abox_candidate(lo, hi, ray, inv, t_min, t_max, &t, &entry)) consider(best, t, entry, index, 0.0f, 0.0f);
     } else {
         F3 center = f3(r0.x, r0.y, r0.z), half = f3(r0.w, r1.x, r1.y);
         Rotor rot{r1.z, r1.w, r2.x, r2.y};
         Ray local = cube_local_ray(center, rot, ray);
         float t;
         bool entry;
-        if (abox_candidate(center - half, center + half, local, t_min, t_max, &t, &entry))
+        F3 linv = f3(1.0f / local.d.x, 1.0f / local.d.y, 1.0f / local.d.z);
+        if (abox_candidate(center - half, center + half, local, linv, t_min, t_max, &t, &entry))
             consider(best, t, entry, index, 0.0f, 0.0f);
     }
 }
@@ -184,35 +185,26 @@ RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, const Best &best, 
     }
 }
 
-// Per-lane traversal stack: the first RT_LDS_STACK entries of a lane live in LDS
-// (entry-major, so the 64 lanes of a wave hit 64 consecutive dwords), deeper ones
-// in an HBM area with the same entry-major layout over all lanes of the grid.
+// Per-lane traversal stack of (child word, entry distance) pairs: the first RT_LDS_STACK
+// entries of a lane live in LDS (entry-major, 8-byte entries, so the lanes of a wave hit
+// consecutive banks), deeper ones in an HBM area with the same layout over all lanes of the grid.
 struct Stack {
-    uint32_t *lds_w;  // [RT_LDS_STACK][block threads], this thread's column
-    float *lds_t;
+    uint2 *lds;  // [RT_LDS_STACK][block threads], this thread's column
     uint32_t lds_stride;
     uint2 *ovf;  // [max_stack - RT_LDS_STACK][grid threads], this thread's column
     size_t ovf_stride;
     int sp;
-    RT_DEV void push(uint32_t w, float t) {
-        if (sp < RT_LDS_STACK) {
-            lds_w[sp * lds_stride] = w;
-            lds_t[sp * lds_stride] = t;
-        } else {
-            ovf[(size_t)(sp - RT_LDS_STACK) * ovf_stride] = make_uint2(w, __float_as_uint(t));
-        }
-        sp++;
+    RT_DEV void store(int slot, uint32_t w, float t) {
+        if (slot < RT_LDS_STACK)
+            lds[slot * lds_stride] = make_uint2(w, __float_as_uint(t));
+        else
+            ovf[(size_t)(slot - RT_LDS_STACK) * ovf_stride] = make_uint2(w, __float_as_uint(t));
     }
     RT_DEV void pop(uint32_t *w, float *t) {
         sp--;
-        if (sp < RT_LDS_STACK) {
-            *w = lds_w[sp * lds_stride];
-            *t = lds_t[sp * lds_stride];
-        } else {
-            uint2 e = ovf[(size_t)(sp - RT_LDS_STACK) * ovf_stride];
-            *w = e.x;
-            *t = __uint_as_float(e.y);
-        }
+        uint2 e = (sp < RT_LDS_STACK) ? lds[sp * lds_stride] : ovf[(size_t)(sp - RT_LDS_STACK) * ovf_stride];
+        *w = e.x;
+        *t = __uint_as_float(e.y);
     }
 };
 
@@ -279,7 +271,7 @@ RT_DEV bool traversal_leaf_step(const RtSceneView &sc, Traversal &tr, Stack &st,
     int32_t count = (int32_t)((entry >> 28) & 7u) + 1;
     for (int32_t k = 0; k < count; k++) {
         if (COUNT) (*tests)++;
-        test_primitive(prims, first + k, tr.ray, t_min, t_max, tr.best);
+        test_primitive(prims, first + k, tr.ray, tr.inv, t_min, t_max, tr.best);
     }
     return traversal_pop(tr, st);
 }
@@ -288,25 +280,38 @@ RT_DEV bool traversal_leaf_step(const RtSceneView &sc, Traversal &tr, Stack &st,
 // nearest (or pops).  Returns true when the traversal is finished.
 template <bool COUNT>
 RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
-    const float4 *__restrict__ nodes = (const float4 *)sc.nodes;
+    const char *__restrict__ nodes = (const char *)sc.nodes;
     const Ray &ray = tr.ray;
     const F3 inv = tr.inv;
-    const float4 *n = nodes + (size_t)tr.entry * RT_NODE_FLOAT4S;
-    float4 lox = n[0], loy = n[1], loz = n[2], hix = n[3], hiy = n[4], hiz = n[5];
-    float4 cwf = n[6];
+    // 32-bit byte offsets from the (uniform) node array base
+    const uint32_t base = tr.entry * (RT_NODE_FLOAT4S * 16u);
+    const float4 nx4 = *(const float4 *)(nodes + (base + 0u));
+    const float4 ny4 = *(const float4 *)(nodes + (base + 16u));
+    const float4 nz4 = *(const float4 *)(nodes + (base + 32u));
+    const float4 fx4 = *(const float4 *)(nodes + (base + 48u));
+    const float4 fy4 = *(const float4 *)(nodes + (base + 64u));
+    const float4 fz4 = *(const float4 *)(nodes + (base + 80u));
+    const float4 cwf = *(const float4 *)(nodes + (base + 96u));
     if (COUNT) (*visits)++;
     uint32_t cw[4] = {__float_as_uint(cwf.x), __float_as_uint(cwf.y), __float_as_uint(cwf.z), __float_as_uint(cwf.w)};
-    float lx[4] = {lox.x, lox.y, lox.z, lox.w}, ly[4] = {loy.x, loy.y, loy.z, loy.w}, lz[4] = {loz.x, loz.y, loz.z, loz.w};
-    float hx[4] = {hix.x, hix.y, hix.z, hix.w}, hy[4] = {hiy.x, hiy.y, hiy.z, hiy.w}, hz[4] = {hiz.x, hiz.y, hiz.z, hiz.w};
+    float ax[4] = {nx4.x, nx4.y, nx4.z, nx4.w}, ay[4] = {ny4.x, ny4.y, ny4.z, ny4.w}, az[4] = {nz4.x, nz4.y, nz4.z, nz4.w};
+    float bx[4] = {fx4.x, fx4.y, fx4.z, fx4.w}, by[4] = {fy4.x, fy4.y, fy4.z, fy4.w}, bz[4] = {fz4.x, fz4.y, fz4.z, fz4.w};
     float key[4];
     const float kInf = __int_as_float(0x7f800000);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        float t0x = (lx[c] - ray.o.x) * inv.x, t1x = (hx[c] - ray.o.x) * inv.x;
-        float t0y = (ly[c] - ray.o.y) * inv.y, t1y = (hy[c] - ray.o.y) * inv.y;
-        float t0z = (lz[c] - ray.o.z) * inv.z, t1z = (hz[c] - ray.o.z) * inv.z;
-        float tn = fmaxf(fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z)), t_min);
-        float tf = fminf(fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z)), tr.best.t);
+        // the reference's t0 = (min - o) * inv, t1 = (max - o) * inv and their per-axis min / max
+        // (src/tracer/cube.rs:164-168).  Loading the planes pre-ordered by the ray's direction signs
+        // would save the six min/max, but the three extra per-ray registers spill at 6 waves/SIMD
+        // and the kernel ran 13 % slower.
+        float t0x = (ax[c] - ray.o.x) * inv.x, t1x = (bx[c] - ray.o.x) * inv.x;
+        float t0y = (ay[c] - ray.o.y) * inv.y, t1y = (by[c] - ray.o.y) * inv.y;
+        float t0z = (az[c] - ray.o.z) * inv.z, t1z = (bz[c] - ray.o.z) * inv.z;
+        float nxv = fminf(t0x, t1x), fxv = fmaxf(t0x, t1x);
+        float nyv = fminf(t0y, t1y), fyv = fmaxf(t0y, t1y);
+        float nzv = fminf(t0z, t1z), fzv = fmaxf(t0z, t1z);
+        float tn = fmaxf(fmaxf(fmaxf(nxv, nyv), nzv), t_min);
+        float tf = fminf(fminf(fminf(fxv, fyv), fzv), tr.best.t);
         bool hit = (cw[c] != RT_CHILD_NONE) && (tn <= tf);
         key[c] = hit ? tn : kInf;
     }
@@ -322,10 +327,22 @@ RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st,
     }
     RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
-    if (key[3] < kInf) st.push(cw[3], key[3]);
-    if (key[2] < kInf) st.push(cw[2], key[2]);
-    if (key[1] < kInf) st.push(cw[1], key[1]);
-    if (key[0] < kInf) {
+    // hits are key[0 .. nh); the nearest continues, the others go on the stack far to near
+    const int nh = (int)(key[0] < kInf) + (int)(key[1] < kInf) + (int)(key[2] < kInf) + (int)(key[3] < kInf);
+    if (nh > 1) {
+        const int top = st.sp + nh - 1;
+        if (top <= RT_LDS_STACK) {
+            if (nh > 1) st.lds[(top - 1) * st.lds_stride] = make_uint2(cw[1], __float_as_uint(key[1]));
+            if (nh > 2) st.lds[(top - 2) * st.lds_stride] = make_uint2(cw[2], __float_as_uint(key[2]));
+            if (nh > 3) st.lds[(top - 3) * st.lds_stride] = make_uint2(cw[3], __float_as_uint(key[3]));
+        } else {
+            if (nh > 1) st.store(top - 1, cw[1], key[1]);
+            if (nh > 2) st.store(top - 2, cw[2], key[2]);
+            if (nh > 3) st.store(top - 3, cw[3], key[3]);
+        }
+        st.sp = top;
+    }
+    if (nh > 0) {
         tr.entry = cw[0];
         return false;
     }

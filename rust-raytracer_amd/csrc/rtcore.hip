@@ -110,14 +110,12 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     extend_kernel(RtSceneView sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
                   const uint32_t *__restrict__ count_ptr, uint32_t n_fixed, float t_min, float t_max,
                   float4 *__restrict__ hit, uint2 *ovf, uint32_t *head, unsigned long long *counters) {
-    __shared__ uint32_t s_w[RT_LDS_STACK * kBlock];
-    __shared__ float s_t[RT_LDS_STACK * kBlock];
+    __shared__ uint2 s_stack[RT_LDS_STACK * kBlock];
     const uint32_t n = count_ptr ? *count_ptr : n_fixed;
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     Stack st;
-    st.lds_w = s_w + threadIdx.x;
-    st.lds_t = s_t + threadIdx.x;
+    st.lds = s_stack + threadIdx.x;
     st.lds_stride = kBlock;
     st.ovf = ovf + (blockIdx.x * blockDim.x + threadIdx.x);
     st.ovf_stride = (size_t)gridDim.x * blockDim.x;
