@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--tris", type=int, default=10_000_000)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--rays", type=int, default=100_000_000, help="closest_hit workload: rays per step")
     ap.add_argument("--batch-paths", type=int, default=0)
