@@ -184,6 +184,8 @@ def main():
         value = rays_total / elapsed_max / 1e6
         extend_s = st.extend_ms / 1e3
         achieved = (st.rays * bytes_per_ray / extend_s / 1e9) if extend_s > 0 else 0.0
+        launches = max(1, int(st.extend_launches))
+        traffic, traffic_note = measured_traffic(args, info)
         out = {
             "metric": "Mrays/s (extend+shade)",
             "value": round(value, 2),
@@ -215,7 +217,11 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
+                "launches": launches,
+                "mean_launch_ms": round(st.extend_ms / launches, 3),
+                "algorithmic_bytes_per_launch": int(st.rays * bytes_per_ray / launches),
                 "bytes_per_ray": round(bytes_per_ray, 1),
                 "node_visits_per_ray": round(visits_per_ray, 2),
                 "prim_tests_per_ray": round(tests_per_ray, 2),
@@ -231,6 +237,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(args, info):
+    """HBM bytes per closest-hit launch from the PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE in its
+    own run, summarised by tools/extend_pmc_json.py), or None when no profile of this configuration is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_extend_pmc_c4_default.json")
+    default_cfg = (args.workload == "mesh" and args.tris == 10_000_000 and (args.width, args.height) == (3840, 2160)
+                   and args.spp == 16 and args.bounces == 8 and args.batch_paths == 0)
+    if not (default_cfg and os.path.exists(path)):
+        return None, "no PMC profile committed for this configuration"
+    p = json.load(open(path))
+    return (int(p["hbm_bytes_per_launch_corrected"]),
+            "bytes per launch from %s: FETCH_SIZE x 1 KiB x 2 (gfx950 reports half the bytes of 16 B/lane reads; "
+            "calibrated on coalesced streams, this kernel gathers one line per lane); raw %d" % (
+                os.path.relpath(path, ROOT), int(p["hbm_bytes_per_launch_raw"])))
 
 
 def cpu_baseline(pkg, desc, args, W, H, spp, bounces, info):

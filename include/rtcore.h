@@ -188,6 +188,7 @@ typedef struct RtStats {
     double extend_ms; /* device time in the closest-hit stage, when timing was requested */
     double shade_ms;
     double other_ms;
+    uint64_t extend_launches; /* closest-hit kernel launches the times above cover */
 } RtStats;
 
 /* Library / device bring-up.  device < 0 keeps the current HIP device. */

@@ -126,6 +126,7 @@ class RtStats(C.Structure):
         ("extend_ms", C.c_double),
         ("shade_ms", C.c_double),
         ("other_ms", C.c_double),
+        ("extend_launches", C.c_uint64),
     ]
 
 
