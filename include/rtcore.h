@@ -249,6 +249,19 @@ int rt_set_stage_timing(RtScene *scene, int enabled);
 int rt_set_counting(RtScene *scene, int enabled);
 
 /*
+ * Display side, on the device (no scene needed; device pointers, no host synchronisation).
+ * rt_tonemap_device: argb[i] = to_rgb(&(rgb[i] / divisor), inv_gamma), the per-pass display transform of
+ * src/main.rs:266-271 (divisor = passes so far) and the final one of src/main.rs:134-137 (divisor = 1).
+ * rt_bilateral_filter_device: one iteration of bilateral_filter over the frame (src/filter.rs:14-48); the
+ * reference runs three, with (diameter, sigma_i, sigma_s) = (9/i, 0.05/i, 1/i), i = 1..3 (src/main.rs:114-132).
+ * in and out must not alias.
+ */
+int rt_tonemap_device(const float *d_rgb, size_t n_pixels, float divisor, float inv_gamma, uint32_t *d_argb,
+                      void *stream);
+int rt_bilateral_filter_device(const float *d_in, float *d_out, uint32_t width, uint32_t height, uint32_t diameter,
+                               float sigma_i, float sigma_s, void *stream);
+
+/*
  * Host-side helpers that need no device: the reference's display transform,
  * kept here so a host without the Rust crate can drain the core.
  * to_rgb(&Vec3, gamma) -> 0xFFRRGGBB (src/render.rs:39-55).

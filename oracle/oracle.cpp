@@ -1155,4 +1155,44 @@ uint32_t oracle_to_rgb(const float rgb[3], float gamma) {
            ((uint32_t)(o.z * 255.4f));
 }
 
+void oracle_to_rgb_array(const float *rgb, size_t n, float divisor, float gamma, uint32_t *out) {
+    for (size_t i = 0; i < n; i++) {
+        float c[3] = {rgb[3 * i] / divisor, rgb[3 * i + 1] / divisor, rgb[3 * i + 2] / divisor};
+        out[i] = oracle_to_rgb(c, gamma);
+    }
+}
+
+// bilateral_filter over a whole frame: src/filter.rs:4-48, driven as src/main.rs:117-130.  The index
+// arithmetic is the wrapping u32 arithmetic of the reference's release build.
+void oracle_bilateral_filter(const float *img, float *out, uint32_t w, uint32_t h, uint32_t diameter, float sigma_i,
+                             float sigma_s) {
+    auto gaussian = [](float x, float sigma) { return std::exp(-(x * x) / (2.0f * sigma * sigma)) / (2.0f * PI * sigma * sigma); };
+    const uint32_t half = diameter / 2;
+    for (uint32_t cur = 0; cur < w * h; cur++) {
+        uint32_t x = cur % w, y = cur / w;
+        Vec3 pixel(img[3 * cur], img[3 * cur + 1], img[3 * cur + 2]);
+        float current_sum = pixel.x + pixel.y + pixel.z;
+        float sum_scale = 1.0f / 3.0f;
+        Vec3 filtered(0, 0, 0);
+        float pixel_weight = 0.0f;
+        for (uint32_t i = 0; i < diameter; i++) {
+            for (uint32_t j = 0; j < diameter; j++) {
+                uint32_t xn = x - (half - i), yn = y - (half - j);
+                xn = xn > w - 1 ? w - 1 : xn;  // clamp(0, w - 1) on a u32
+                yn = yn > h - 1 ? h - 1 : yn;
+                size_t k = (size_t)yn * w + xn;
+                Vec3 neighbor(img[3 * k], img[3 * k + 1], img[3 * k + 2]);
+                float neighbor_sum = neighbor.x + neighbor.y + neighbor.z;
+                uint32_t dx = x - xn, dy = y - yn;
+                float dist = std::sqrt((float)(dx * dx + dy * dy));
+                float weight = gaussian(sum_scale * (neighbor_sum - current_sum), sigma_i) * gaussian(dist, sigma_s);
+                filtered = filtered + neighbor * weight;
+                pixel_weight += weight;
+            }
+        }
+        Vec3 r = filtered / pixel_weight;
+        out[3 * cur] = r.x, out[3 * cur + 1] = r.y, out[3 * cur + 2] = r.z;
+    }
+}
+
 }  // extern "C"

@@ -687,6 +687,9 @@ void collect_timing(RtScene *s) {
 
 }  // namespace
 
+// lets the other translation units of the library report through rt_last_error()
+extern "C" int rt_set_error_message(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+
 extern "C" {
 
 const char *rt_last_error(void) { return g_error.c_str(); }

@@ -148,3 +148,13 @@ def to_rgb(color, inv_gamma):
     """to_rgb (src/render.rs:39-45): packed 0xFFRRGGBB after ACES + gamma."""
     c = (C.c_float * 3)(*[float(x) for x in color])
     return int(_abi.load().rt_to_rgb(c, float(inv_gamma)))
+
+
+def tonemap_device(d_rgb, n_pixels, divisor, inv_gamma, d_argb, stream=0):
+    """to_rgb(color / divisor, inv_gamma) for a whole frame on the device (src/render.rs:39-55, src/main.rs:266-271)."""
+    _abi.check(_abi.load().rt_tonemap_device(d_rgb, n_pixels, divisor, inv_gamma, d_argb, stream))
+
+
+def bilateral_filter_device(d_in, d_out, width, height, diameter, sigma_i, sigma_s, stream=0):
+    """One iteration of bilateral_filter on the device (src/filter.rs:14-48)."""
+    _abi.check(_abi.load().rt_bilateral_filter_device(d_in, d_out, width, height, diameter, sigma_i, sigma_s, stream))

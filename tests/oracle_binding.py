@@ -52,6 +52,8 @@ def lib():
         L.oracle_path_key.argtypes = [C.c_uint32] * 3
         L.oracle_to_rgb.restype = C.c_uint32
         L.oracle_to_rgb.argtypes = [C.c_void_p, C.c_float]
+        L.oracle_to_rgb_array.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p]
+        L.oracle_bilateral_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
         _lib = L
     return _lib
 
