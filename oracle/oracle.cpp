@@ -1003,12 +1003,22 @@ int oracle_closest_hit_batch(OracleScene *s, const float *org_dir, float t_min, 
 }
 
 // Renderer::render: src/render.rs:162-219
+int oracle_render_range(OracleScene *s, const RtRenderParams *p, uint64_t first_pixel, uint64_t n_pixels, float *accum,
+                        int threads);
 int oracle_render_pass(OracleScene *s, const RtRenderParams *p, float *accum, int threads) {
+    if (!p) return RT_ERR_INVALID_ARGUMENT;
+    return oracle_render_range(s, p, 0, (uint64_t)p->width * p->height, accum, threads);
+}
+// The same for pixels [first_pixel, first_pixel + n_pixels) of the frame only; `accum` still addresses the
+// whole frame.  Lets a test spot-check rows of a frame too large to render on the CPU.
+int oracle_render_range(OracleScene *s, const RtRenderParams *p, uint64_t first_pixel, uint64_t n_pixels, float *accum,
+                        int threads) {
     if (!s || !p || !accum || p->width < 2 || p->height < 2 || p->samples == 0) return RT_ERR_INVALID_ARGUMENT;
     const uint32_t W = p->width, H = p->height, spp = p->samples;
+    if (first_pixel + n_pixels > (uint64_t)W * H) return RT_ERR_INVALID_ARGUMENT;
     Camera cam(s->camera, (float)W / (float)H);
-    parallel_chunks((size_t)W * H, threads, [&](size_t lo, size_t hi) {
-        for (size_t pixel = lo; pixel < hi; pixel++) {
+    parallel_chunks((size_t)n_pixels, threads, [&](size_t lo, size_t hi) {
+        for (size_t pixel = first_pixel + lo; pixel < first_pixel + hi; pixel++) {
             float x = (float)(pixel % W);
             float y = (float)(H - 1 - pixel / W);
             Vec3 pixel_color(0, 0, 0);

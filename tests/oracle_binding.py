@@ -52,6 +52,8 @@ def lib():
         L.oracle_path_key.argtypes = [C.c_uint32] * 3
         L.oracle_to_rgb.restype = C.c_uint32
         L.oracle_to_rgb.argtypes = [C.c_void_p, C.c_float]
+        L.oracle_render_range.restype = C.c_int
+        L.oracle_render_range.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         L.oracle_to_rgb_array.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p]
         L.oracle_bilateral_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
         _lib = L
@@ -111,6 +113,10 @@ class OracleScene:
 
     def render_pass(self, accum, params, threads=None):
         rc = lib().oracle_render_pass(self._h, C.byref(params), _p(accum), threads or default_threads())
+        assert rc == 0, rc
+
+    def render_range(self, accum, params, first_pixel, n_pixels, threads=None):
+        rc = lib().oracle_render_range(self._h, C.byref(params), first_pixel, n_pixels, _p(accum), threads or default_threads())
         assert rc == 0, rc
 
     def preview(self, out, params, threads=None):

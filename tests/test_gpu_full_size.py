@@ -1,0 +1,80 @@
+"""Full-size runs (the sizes BASELINE.json names) checked through properties that do not need a full CPU render:
+rows of a 4K pass spot-checked bit for bit by the oracle, counters that must add up, and the 100 M-ray
+closest-hit batch checked on an oracle subsample plus run-to-run and chunking invariance of its id checksum."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_4k_pass_rows_match_oracle(pkg, oracle):
+    import torch
+
+    d = pkg.scenes.mesh_scene(n_triangles=1_000_000, seed=7)
+    scene, ora = pkg.Scene(d), oracle.OracleScene(d)
+    W, H, spp, bounces = 3840, 2160, 4, 8
+    p = pkg.Scene.params(W, H, spp, bounces, pass_index=3, seed=99)
+    accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    scene.stats()
+    scene.render_pass_device(accum.data_ptr(), p, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = scene.stats()
+    got = accum.cpu().numpy()
+    assert np.isfinite(got).all() and got.min() >= 0.0
+    assert st.paths == W * H * spp and st.paths <= st.rays <= st.paths * bounces
+    want = np.zeros(W * H * 3, np.float32)
+    spans = [(0, 400), (1080 * W + 1000, 600), (2159 * W + 3000, 840), (777 * W + 3838, 4)]  # first, middle, last rows, a row seam
+    for first, count in spans:
+        ora.render_range(want, p, first, count)
+        a, b = got[3 * first:3 * (first + count)], want[3 * first:3 * (first + count)]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (first, np.abs(a - b).max())
+    # a second pass adds to the accumulator (passes sum, the caller divides)
+    p2 = pkg.Scene.params(W, H, spp, bounces, pass_index=4, seed=99)
+    scene.render_pass_device(accum.data_ptr(), p2, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got2 = accum.cpu().numpy()
+    first, count = spans[1]
+    ora.render_range(want, p2, first, count)
+    assert np.array_equal(got2[3 * first:3 * (first + count)].view(np.uint32), want[3 * first:3 * (first + count)].view(np.uint32))
+
+
+def test_100m_ray_batch(pkg, oracle):
+    import math
+    import torch
+
+    d = pkg.scenes.mesh_scene(n_triangles=1_000_000, seed=7)
+    scene, ora = pkg.Scene(d), oracle.OracleScene(d)
+    info = scene.info()
+    n = 100_000_000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x5EED)
+    mn, mx = np.array(info.bounds_min[:]), np.array(info.bounds_max[:])
+    c = torch.tensor((mn + mx) / 2, device="cuda", dtype=torch.float32)
+    h = torch.tensor((mx - mn) / 2 * 1.5, device="cuda", dtype=torch.float32)
+    rays = torch.empty((n, 6), dtype=torch.float32, device="cuda")
+    rays[:, 0:3] = c + (torch.rand((n, 3), device="cuda", generator=g) * 2 - 1) * h
+    z = torch.rand(n, device="cuda", generator=g) * 2 - 1
+    ph = torch.rand(n, device="cuda", generator=g) * (2 * math.pi)
+    rr = torch.sqrt(torch.clamp(1 - z * z, min=0))
+    rays[:, 3], rays[:, 4], rays[:, 5] = rr * torch.cos(ph), rr * torch.sin(ph), z
+    del z, ph, rr
+    ids = torch.empty(n, dtype=torch.int32, device="cuda")
+    t = torch.empty(n, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    scene.closest_hit_device(rays.data_ptr(), n, ids.data_ptr(), t.data_ptr(), None, None, stream)
+    torch.cuda.synchronize()
+    first = ids.clone()
+    scene.closest_hit_device(rays.data_ptr(), n, ids.data_ptr(), t.data_ptr(), None, None, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(first, ids)  # run-to-run invariance of all 100 M ids
+    checksum = zlib.crc32(ids[:10_000_000].cpu().numpy().tobytes())
+    assert checksum == zlib.crc32(first[:10_000_000].cpu().numpy().tobytes())
+    hit_fraction = float((ids >= 0).float().mean())
+    assert 0.2 < hit_fraction < 1.0
+    sub = torch.randint(0, n, (1_000_000,), device="cuda", generator=g)
+    r_sub = rays[sub].cpu().numpy()
+    oids, ot, _, _ = ora.closest_hit(r_sub)
+    assert int((ids[sub].cpu().numpy() != oids).sum()) == 0  # 0 id mismatches on the 1 M-ray subsample
+    assert np.array_equal(t[sub].cpu().numpy().view(np.uint32), ot.view(np.uint32))
