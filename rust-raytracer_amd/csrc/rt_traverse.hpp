@@ -294,22 +294,31 @@ RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st,
     const float4 cwf = *(const float4 *)(nodes + (base + 96u));
     if (COUNT) (*visits)++;
     uint32_t cw[4] = {__float_as_uint(cwf.x), __float_as_uint(cwf.y), __float_as_uint(cwf.z), __float_as_uint(cwf.w)};
-    float ax[4] = {nx4.x, nx4.y, nx4.z, nx4.w}, ay[4] = {ny4.x, ny4.y, ny4.z, ny4.w}, az[4] = {nz4.x, nz4.y, nz4.z, nz4.w};
-    float bx[4] = {fx4.x, fx4.y, fx4.z, fx4.w}, by[4] = {fy4.x, fy4.y, fy4.z, fy4.w}, bz[4] = {fz4.x, fz4.y, fz4.z, fz4.w};
+    // the reference's t0 = (min - o) * inv, t1 = (max - o) * inv (src/tracer/cube.rs:164-165) for two
+    // children at a time: gfx950 subtracts and multiplies two floats per instruction
+    // (v_pk_add_f32 / v_pk_mul_f32, IEEE results, no contraction), min / max have no packed form.
+    typedef float Pair __attribute__((ext_vector_type(2)));
+    const Pair ox = {ray.o.x, ray.o.x}, oy = {ray.o.y, ray.o.y}, oz = {ray.o.z, ray.o.z};
+    const Pair ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const Pair t0x[2] = {(Pair{nx4.x, nx4.y} - ox) * ix, (Pair{nx4.z, nx4.w} - ox) * ix};
+    const Pair t1x[2] = {(Pair{fx4.x, fx4.y} - ox) * ix, (Pair{fx4.z, fx4.w} - ox) * ix};
+    const Pair t0y[2] = {(Pair{ny4.x, ny4.y} - oy) * iy, (Pair{ny4.z, ny4.w} - oy) * iy};
+    const Pair t1y[2] = {(Pair{fy4.x, fy4.y} - oy) * iy, (Pair{fy4.z, fy4.w} - oy) * iy};
+    const Pair t0z[2] = {(Pair{nz4.x, nz4.y} - oz) * iz, (Pair{nz4.z, nz4.w} - oz) * iz};
+    const Pair t1z[2] = {(Pair{fz4.x, fz4.y} - oz) * iz, (Pair{fz4.z, fz4.w} - oz) * iz};
     float key[4];
     const float kInf = __int_as_float(0x7f800000);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        // the reference's t0 = (min - o) * inv, t1 = (max - o) * inv and their per-axis min / max
-        // (src/tracer/cube.rs:164-168).  Loading the planes pre-ordered by the ray's direction signs
-        // would save the six min/max, but the three extra per-ray registers spill at 6 waves/SIMD
-        // and the kernel ran 13 % slower.
-        float t0x = (ax[c] - ray.o.x) * inv.x, t1x = (bx[c] - ray.o.x) * inv.x;
-        float t0y = (ay[c] - ray.o.y) * inv.y, t1y = (by[c] - ray.o.y) * inv.y;
-        float t0z = (az[c] - ray.o.z) * inv.z, t1z = (bz[c] - ray.o.z) * inv.z;
-        float nxv = fminf(t0x, t1x), fxv = fmaxf(t0x, t1x);
-        float nyv = fminf(t0y, t1y), fyv = fmaxf(t0y, t1y);
-        float nzv = fminf(t0z, t1z), fzv = fmaxf(t0z, t1z);
+        // per-axis min / max of the two plane distances and the interval test (src/tracer/cube.rs:166-170).
+        // Loading the planes pre-ordered by the ray's direction signs would save the six min/max, but
+        // the three extra per-ray registers spill at 6 waves/SIMD and the kernel ran 13 % slower.
+        const float ax0 = t0x[c >> 1][c & 1], ax1 = t1x[c >> 1][c & 1];
+        const float ay0 = t0y[c >> 1][c & 1], ay1 = t1y[c >> 1][c & 1];
+        const float az0 = t0z[c >> 1][c & 1], az1 = t1z[c >> 1][c & 1];
+        float nxv = fminf(ax0, ax1), fxv = fmaxf(ax0, ax1);
+        float nyv = fminf(ay0, ay1), fyv = fmaxf(ay0, ay1);
+        float nzv = fminf(az0, az1), fzv = fmaxf(az0, az1);
         float tn = fmaxf(fmaxf(fmaxf(nxv, nyv), nzv), t_min);
         float tf = fminf(fminf(fminf(fxv, fyv), fzv), tr.best.t);
         bool hit = (cw[c] != RT_CHILD_NONE) && (tn <= tf);
