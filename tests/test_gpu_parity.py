@@ -207,3 +207,34 @@ def test_ray_count_matches_oracle(pkg, oracle):
     ora.render_pass(oacc, p)
     assert st.paths == W * H * 4
     assert st.rays == ora.counters()["rays"]
+
+
+@pytest.mark.parametrize(
+    "W,H,spp,bounces,batch",
+    [
+        (2, 2, 1, 0, 0),        # smallest frame the reference accepts (W-1, H-1 divide), no bounce at all: 0.01 everywhere
+        (3, 5, 7, 1, 0),        # odd sizes, one bounce
+        (64, 48, 33, 8, 1000),  # batches that split pixels' sample runs (33 spp, 1000 paths per batch)
+        (17, 13, 4, 50, 1),     # deep paths, the smallest batch
+        (640, 3, 2, 8, 0),      # wide and flat
+    ],
+)
+def test_render_pass_parameter_edges(pkg, oracle, W, H, spp, bounces, batch):
+    d = pkg.scenes.rtiow(seed=3)
+    scene, ora = pkg.Scene(d), oracle.OracleScene(d)
+    acc = np.full(W * H * 3, 0.25, np.float32)  # the pass adds to what the buffer holds
+    oacc = acc.copy()
+    p = pkg.Scene.params(W, H, spp, bounces, pass_index=7, seed=11, batch_paths=batch)
+    scene.render_pass(acc, p)
+    ora.render_pass(oacc, p)
+    assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))
+    if bounces == 0:
+        assert np.allclose(acc, 0.25 + 0.01)
+
+
+def test_render_pass_rejects_bad_parameters(pkg):
+    scene = pkg.Scene(pkg.scenes.cornell())
+    for W, H, spp in ((1, 16, 1), (16, 1, 1), (16, 16, 0), (0, 0, 1)):
+        acc = np.zeros(W * H * 3, np.float32)
+        with pytest.raises(pkg.RtError):
+            scene.render_pass(acc, pkg.Scene.params(W, H, spp, 8))
