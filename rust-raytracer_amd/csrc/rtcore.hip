@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     st.ovf_stride = (size_t)gridDim.x * blockDim.x;
     st.sp = 0;
     uint32_t visits = 0, tests = 0;
-    unsigned long long dbg[4] = {0, 0, 0, 0};  // leaf steps, lanes in them, node steps, lanes in them (lane 0 of each wave)
+    unsigned long long dbg[6] = {0, 0, 0, 0, 0, 0};  // leaf steps, lanes in them, node steps, lanes in them, lanes without a ray over all steps, refills (lane 0 of each wave)
     Traversal tr;
     int32_t ray_i = -1;     // ray this lane works on, -1 = none
     bool parked = false;    // traversal finished, result not yet written
@@ -134,6 +134,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         const unsigned long long idle_mask = __ballot(parked || ray_i < 0);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
         if (n_idle >= kServiceLanes && (parked_mask != 0ull || !no_more)) {
+            if (COUNT && lane == 0) dbg[5]++;
             if (parked) {
                 hit[ray_i] = make_float4(tr.best.t, __int_as_float(tr.best.index), tr.best.u, tr.best.v);
                 parked = false;
@@ -193,6 +194,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         if (COUNT && lane == 0) {  // occupancy of the two step kinds, for tuning
             if (run_leaf && n_leaf) dbg[0]++, dbg[1] += n_leaf;
             if (run_node && n_node) dbg[2]++, dbg[3] += n_node;
+            dbg[4] += 64u - n_leaf - n_node;
         }
         if (run_leaf && at_leaf) parked = traversal_leaf_step<COUNT>(sc, tr, st, t_min, t_max, &tests);
         if (run_node && at_node) parked = traversal_node_step<COUNT>(sc, tr, st, t_min, &visits);
@@ -201,7 +203,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         atomicAdd(&counters[0], (unsigned long long)visits);
         atomicAdd(&counters[1], (unsigned long long)tests);
         if (lane == 0)
-            for (int k = 0; k < 4; k++) atomicAdd(&counters[2 + k], dbg[k]);
+            for (int k = 0; k < 6; k++) atomicAdd(&counters[2 + k], dbg[k]);
     }
 }
 
@@ -830,13 +832,16 @@ int rt_scene_stats(const RtScene *cs, RtStats *out) {
         RT_HIP(hipMemset(s->totals.p, 0, 64));
     }
     if (s->counters.p) {
-        unsigned long long c[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         RT_HIP(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         s->stats.node_visits += c[0];
         s->stats.prim_tests += c[1];
         if (std::getenv("RTCORE_DEBUG_STEPS") && c[2] + c[4])
-            std::fprintf(stderr, "[rtcore] leaf steps %llu with %.1f lanes, node steps %llu with %.1f lanes\n", c[2],
-                         c[2] ? (double)c[3] / (double)c[2] : 0.0, c[4], c[4] ? (double)c[5] / (double)c[4] : 0.0);
+            std::fprintf(stderr,
+                         "[rtcore] leaf steps %llu with %.1f lanes, node steps %llu with %.1f lanes, %.1f lanes without a ray "
+                         "per step, %llu refills\n",
+                         c[2], c[2] ? (double)c[3] / (double)c[2] : 0.0, c[4], c[4] ? (double)c[5] / (double)c[4] : 0.0,
+                         (double)c[6] / (double)(c[2] + c[4]), c[7]);
         RT_HIP(hipMemset(s->counters.p, 0, 64));
     }
     *out = s->stats;
