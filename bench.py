@@ -12,7 +12,7 @@ Prints ONE JSON line on rank 0:
   value        Mrays/s of the whole job: Bvh::hit invocations (primary rays + every continued
                bounce) of all ranks / max-over-ranks wall time of the K steps
   roofline     closest-hit ("extend") kernel: algorithmic bytes per ray (node visits x 128 B +
-               primitive tests x 48 B + 32 B ray in + 16 B hit out, visits/tests counted by the
+               primitive tests x 48 B + 32 B ray in + 8 B hit out, visits/tests counted by the
                instrumented kernel on the same workload outside the timed region) x rays per
                launch / mean launch duration (HIP events on the launch stream, timed region)
   cpu_baseline the CPU oracle (a restatement of the reference's renderer, not the Rust binary)
@@ -154,7 +154,7 @@ def main():
     cs = scene.stats()
     visits_per_ray = cs.node_visits / max(1, cs.rays)
     tests_per_ray = cs.prim_tests / max(1, cs.rays)
-    bytes_per_ray = visits_per_ray * info.node_bytes + tests_per_ray * info.primitive_bytes + 32 + 16
+    bytes_per_ray = visits_per_ray * info.node_bytes + tests_per_ray * info.primitive_bytes + 32 + 8
 
     # ---- warmup, then the timed region
     for i in range(args.warmup):

@@ -6,6 +6,7 @@ returns RT_ERR_DEVICE when no HIP device is visible.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RTCORE_LIB selects another build of the same library (kernel tuning experiments)
@@ -178,6 +179,15 @@ def load():
         raise RuntimeError(
             "librtcore.so is not built (%s): run `make -C rust-raytracer_amd` or __graft_entry__.build()" % LIB_PATH
         )
+    # One HIP runtime per process.  PyTorch wheels bundle their own libamdhip64 and ask for it by file name, while
+    # librtcore asks for the soname: a process that loads librtcore first gets the system runtime, a later
+    # `import torch` brings a second one, and torch then finds no device.  With torch imported first the loader
+    # binds librtcore to the runtime torch brought, whose streams and allocations the callers hand in anyway.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

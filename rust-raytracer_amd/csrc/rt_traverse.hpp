@@ -32,17 +32,14 @@ namespace rtd {
 struct Best {
     float t;
     int32_t index;  // visit rank = index into the primitive array, -1 = none
-    float u, v;     // barycentrics when the best is a triangle
     bool ties;      // does the best primitive's own bound check accept t == t_max
 };
 
-RT_DEV void consider(Best &b, float t, bool ties, int32_t index, float u, float v) {
+RT_DEV void consider(Best &b, float t, bool ties, int32_t index) {
     bool closer = (t < b.t) || (t == b.t && ((index > b.index) ? ties : !b.ties));
     if (closer) {
         b.t = t;
         b.index = index;
-        b.u = u;
-        b.v = v;
         b.ties = ties;
     }
 }
@@ -119,7 +116,7 @@ RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, cons
         if (v < 0.0f || u + v > 1.0f) return;
         float t = f * dot(e2, q);
         if (t < t_min || t > t_max) return;
-        consider(best, t, true, index, u, v);
+        consider(best, t, true, index);
     } else if (type == RT_PRIM_SPHERE) {
         // Sphere::hit (src/tracer/sphere.rs:28-58)
         F3 c = f3(r0.x, r0.y, r0.z);
@@ -131,17 +128,17 @@ RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, cons
             float h = sqrtf(disc);
             float temp = -half_b - h;
             if (temp < t_max && temp > t_min) {
-                consider(best, temp, false, index, 0.0f, 0.0f);
+                consider(best, temp, false, index);
                 return;
             }
             temp = -half_b + h;
-            if (temp < t_max && temp > t_min) consider(best, temp, false, index, 0.0f, 0.0f);
+            if (temp < t_max && temp > t_min) consider(best, temp, false, index);
         }
     } else if (type == RT_PRIM_ABOX) {
         F3 lo = f3(r0.x, r0.y, r0.z), hi = f3(r0.w, r1.x, r1.y);
         float t;
         bool entry;
-        if (abox_candidate(lo, hi, ray, inv, t_min, t_max, &t, &entry)) consider(best, t, entry, index, 0.0f, 0.0f);
+        if (abox_candidate(lo, hi, ray, inv, t_min, t_max, &t, &entry)) consider(best, t, entry, index);
     } else {
         F3 center = f3(r0.x, r0.y, r0.z), half = f3(r0.w, r1.x, r1.y);
         Rotor rot{r1.z, r1.w, r2.x, r2.y};
@@ -150,7 +147,7 @@ RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, cons
         bool entry;
         F3 linv = f3(1.0f / local.d.x, 1.0f / local.d.y, 1.0f / local.d.z);
         if (abox_candidate(center - half, center + half, local, linv, t_min, t_max, &t, &entry))
-            consider(best, t, entry, index, 0.0f, 0.0f);
+            consider(best, t, entry, index);
     }
 }
 
@@ -165,11 +162,20 @@ RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, const Best &best, 
     *material = meta >> RT_PRIM_MAT_SHIFT;
     *prim_id = (int32_t)__float_as_uint(r2.w);
     if (type == RT_PRIM_TRIANGLE) {
+        // The traversal carries only (t, rank): the barycentrics of the winning triangle are worked
+        // out again here, by the same operations on the same floats as in test_primitive, so they
+        // are the same bits (src/tracer/triangle.rs:41-58).
+        F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
+        F3 h = cross(ray.d, e2);
+        float f = 1.0f / dot(e1, h);
+        F3 s = ray.o - v0;
+        float u = f * dot(s, h);
+        float v = f * dot(ray.d, cross(s, e1));
         // src/tracer/triangle.rs:68-70
         const float4 *nn = (const float4 *)sc.tri_normals + (size_t)best.index * 3;
         float4 a = nn[0], b = nn[1], c = nn[2];
         F3 n0 = f3(a.x, a.y, a.z), n1 = f3(b.x, b.y, b.z), n2 = f3(c.x, c.y, c.z);
-        *normal = normalized((1.0f - (best.u + best.v)) * n0 + best.u * n1 + best.v * n2);
+        *normal = normalized((1.0f - (u + v)) * n0 + u * n1 + v * n2);
     } else if (type == RT_PRIM_SPHERE) {
         F3 p = ray_at(ray, best.t);
         *normal = normalized(p - f3(r0.x, r0.y, r0.z));
@@ -224,7 +230,6 @@ RT_DEV bool traversal_begin(const RtSceneView &sc, Traversal &tr, Stack &st, flo
                             uint32_t *visits) {
     tr.best.t = t_max;
     tr.best.index = -1;
-    tr.best.u = tr.best.v = 0.0f;
     tr.best.ties = false;
     st.sp = 0;
     tr.entry = 0;  // node 0

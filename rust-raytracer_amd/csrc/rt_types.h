@@ -49,7 +49,7 @@
 
 // LDS entries of the per-lane traversal stack; deeper entries go to an HBM overflow area.
 #ifndef RT_LDS_STACK
-#define RT_LDS_STACK 12
+#define RT_LDS_STACK 11
 #endif
 
 struct RtDevMaterial {  // 32 B

@@ -78,8 +78,8 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
 
 // ---------------------------------------------------------------------------
 // extend: Bvh::hit for every live path (src/tracer/bvh.rs:143)
-// hit = (t, visit rank, u, v)   rank -1 = miss; the consumer completes the HitRecord (normal,
-// material, primitive id) with finish_hit, where all lanes of a wave are busy
+// hit = (t, visit rank)   rank -1 = miss; the consumer completes the HitRecord (barycentrics,
+// normal, material, primitive id) with finish_hit, where all lanes of a wave are busy
 // ---------------------------------------------------------------------------
 // Persistent waves: a wave reserves runs of kRayChunk consecutive ray indices from a global
 // counter and hands them to its lanes; a lane that has finished its ray parks its result, and
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
 #define RT_SERVICE_LANES 24
 #endif
 #ifndef RT_EXTEND_WAVES
-#define RT_EXTEND_WAVES 6
+#define RT_EXTEND_WAVES 7
 #endif
 #ifndef RT_VOTE_ENOUGH
 #define RT_VOTE_ENOUGH 65
@@ -110,7 +110,7 @@ template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     extend_kernel(RtSceneView sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
                   const uint32_t *__restrict__ count_ptr, uint32_t n_fixed, float t_min, float t_max,
-                  float4 *__restrict__ hit, uint2 *ovf, uint32_t *head, unsigned long long *counters) {
+                  float2 *__restrict__ hit, uint2 *ovf, uint32_t *head, unsigned long long *counters) {
     __shared__ uint2 s_stack[RT_LDS_STACK * kBlock];
     const uint32_t n = count_ptr ? *count_ptr : n_fixed;
     const uint32_t lane = threadIdx.x & 63u;
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         if (n_idle >= kServiceLanes && (parked_mask != 0ull || !no_more)) {
             if (COUNT && lane == 0) dbg[5]++;
             if (parked) {
-                hit[ray_i] = make_float4(tr.best.t, __int_as_float(tr.best.index), tr.best.u, tr.best.v);
+                hit[ray_i] = make_float2(tr.best.t, __int_as_float(tr.best.index));
                 parked = false;
                 ray_i = -1;
             }
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
                         if (traversal_begin<COUNT>(sc, tr, st, t_min, t_max, &visits)) {
                             ray_i = (int32_t)i;
                         } else {
-                            hit[i] = make_float4(0.0f, __int_as_float(-1), 0.0f, 0.0f);
+                            hit[i] = make_float2(0.0f, __int_as_float(-1));
                         }
                     }
                 }
@@ -237,7 +237,7 @@ __device__ __forceinline__ uint32_t block_compact_slot(bool alive, uint32_t *cou
 // shade: the body of ray_color's loop (src/render.rs:62-81) for bounce `bounce`
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kShadeBlock)
-    shade_kernel(RtSceneView sc, PathState in, const float4 *__restrict__ hit_a,
+    shade_kernel(RtSceneView sc, PathState in, const float2 *__restrict__ hit_a,
                  const uint32_t *__restrict__ count_in, PathState out, uint32_t *count_out, float4 *__restrict__ rad,
                  uint32_t bounce, uint32_t depth, float light_clamp) {
     __shared__ uint32_t s_counts[kShadeBlock / 64 + 1];
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(kShadeBlock)
             o4 = in.o[i];
             d4 = in.d[i];
             th4 = in.thr[i];
-            float4 ha = hit_a[i];
+            float2 ha = hit_a[i];
             uint32_t slot = __float_as_uint(o4.w);
             uint32_t key = __float_as_uint(th4.w);
             Ray ray;
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(kShadeBlock)
             thr = f3(th4.x, th4.y, th4.z);
             F3 result;
             if (__float_as_int(ha.y) >= 0) {
-                Best best{ha.x, __float_as_int(ha.y), ha.z, ha.w, false};
+                Best best{ha.x, __float_as_int(ha.y), false};
                 F3 nrm;
                 uint32_t mat;
                 int32_t pid;
@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(kShadeBlock)
 
 // normals_only / colors_only / no_bounce (src/render.rs:107-138): every path ends after its first hit
 __global__ void __launch_bounds__(kBlock)
-    shade_first_hit_kernel(RtSceneView sc, PathState in, const float4 *__restrict__ hit_a,
+    shade_first_hit_kernel(RtSceneView sc, PathState in, const float2 *__restrict__ hit_a,
                            const uint32_t *__restrict__ count_in,
                            float4 *__restrict__ rad, int mode) {
     const uint32_t n = *count_in;
@@ -312,14 +312,15 @@ __global__ void __launch_bounds__(kBlock)
     const RtDevMaterial *mats = (const RtDevMaterial *)sc.materials;
     const float kInf = __int_as_float(0x7f800000);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float4 o4 = in.o[i], d4 = in.d[i], th4 = in.thr[i], ha = hit_a[i];
+        float4 o4 = in.o[i], d4 = in.d[i], th4 = in.thr[i];
+        float2 ha = hit_a[i];
         uint32_t slot = __float_as_uint(o4.w);
         Ray ray;
         ray.o = f3(o4.x, o4.y, o4.z);
         ray.d = f3(d4.x, d4.y, d4.z);
         F3 result;
         if (__float_as_int(ha.y) >= 0) {
-            Best best{ha.x, __float_as_int(ha.y), ha.z, ha.w, false};
+            Best best{ha.x, __float_as_int(ha.y), false};
             F3 nrm;
             uint32_t mat;
             int32_t pid;
@@ -399,12 +400,13 @@ __global__ void __launch_bounds__(kBlock)
     rd[i] = make_float4(d.x, d.y, d.z, 0.0f);
 }
 __global__ void __launch_bounds__(kBlock)
-    unpack_hits_kernel(RtSceneView sc, const float4 *__restrict__ hit_a, const float4 *__restrict__ ro,
+    unpack_hits_kernel(RtSceneView sc, const float2 *__restrict__ hit_a, const float4 *__restrict__ ro,
                        const float4 *__restrict__ rd, uint32_t n, int32_t *prim_id, float *t, float *normal,
                        float *point) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float4 ha = hit_a[i], o4 = ro[i], d4 = rd[i];
+    float2 ha = hit_a[i];
+    float4 o4 = ro[i], d4 = rd[i];
     bool ok = __float_as_int(ha.y) >= 0;
     Ray ray;
     ray.o = f3(o4.x, o4.y, o4.z);
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(kBlock)
     uint32_t mat = 0;
     int32_t pid = -1;
     if (ok) {
-        Best best{ha.x, __float_as_int(ha.y), ha.z, ha.w, false};
+        Best best{ha.x, __float_as_int(ha.y), false};
         finish_hit(sc, ray, best, &nrm, &mat, &pid);
     }
     if (prim_id) prim_id[i] = pid;
@@ -502,7 +504,7 @@ int ensure_work(RtScene *s, uint64_t paths) {
         if ((rc = s->st_d[k].ensure(paths * 16))) return rc;
         if ((rc = s->st_thr[k].ensure(paths * 16))) return rc;
     }
-    if ((rc = s->hit_a.ensure(paths * 16))) return rc;
+    if ((rc = s->hit_a.ensure(paths * 8))) return rc;
     if ((rc = s->rad.ensure(paths * 16))) return rc;
     if ((rc = s->counts.ensure(2 * kCountSlots * sizeof(uint32_t)))) return rc;
     if (!s->totals.p) {
@@ -567,11 +569,11 @@ int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4
     StageTimer tm(s, stream, 0);
     if (counted)
         hipLaunchKernelGGL(extend_kernel<true>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
-                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (uint2 *)s->ovf.p, head,
+                           n_upper, t_min, t_max, (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head,
                            (unsigned long long *)s->counters.p);
     else
         hipLaunchKernelGGL(extend_kernel<false>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
-                           n_upper, t_min, t_max, (float4 *)s->hit_a.p, (uint2 *)s->ovf.p, head,
+                           n_upper, t_min, t_max, (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head,
                            (unsigned long long *)s->counters.p);
     RT_HIP(hipGetLastError());
     return RT_OK;
@@ -648,12 +650,12 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
             uint32_t blocks = std::min(blocks_for(n), (uint32_t)s->n_cus * 16u);
             if (first_hit_only) {
                 hipLaunchKernelGGL(shade_first_hit_kernel, dim3(blocks), dim3(kBlock), 0, stream, s->view, st[cur],
-                                   (const float4 *)s->hit_a.p, counts + b, rad,
+                                   (const float2 *)s->hit_a.p, counts + b, rad,
                                    preview && p->mode == RT_MODE_IMAGE ? (int)RT_MODE_IMAGE : (int)p->mode);
             } else {
                 uint32_t sblocks = std::min((n + kShadeBlock - 1) / kShadeBlock, (uint32_t)s->n_cus * 4u);
                 hipLaunchKernelGGL(shade_kernel, dim3(sblocks), dim3(kShadeBlock), 0, stream, s->view, st[cur],
-                                   (const float4 *)s->hit_a.p, counts + b, st[cur ^ 1],
+                                   (const float2 *)s->hit_a.p, counts + b, st[cur ^ 1],
                                    counts + b + 1, rad, b, depth, p->light_clamp);
             }
             cur ^= 1;
@@ -891,7 +893,7 @@ static int closest_hit_device(RtScene *s, const float *d_org_dir, float t_min, f
         {
             StageTimer tm(s, stream, 2);
             hipLaunchKernelGGL(unpack_hits_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream,
-                               s->view, (const float4 *)s->hit_a.p, ro, rd, m,
+                               s->view, (const float2 *)s->hit_a.p, ro, rd, m,
                                d_id ? d_id + off : nullptr, d_t ? d_t + off : nullptr,
                                d_normal ? d_normal + off * 3 : nullptr, d_point ? d_point + off * 3 : nullptr);
         }
