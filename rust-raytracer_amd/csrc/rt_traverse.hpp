@@ -197,18 +197,21 @@ RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, const Best &best, 
 struct Stack {
     uint2 *lds;  // [RT_LDS_STACK][block threads], this thread's column
     uint32_t lds_stride;
-    uint2 *ovf;  // [max_stack - RT_LDS_STACK][grid threads], this thread's column
-    size_t ovf_stride;
+    uint2 *ovf;  // [max_stack - RT_LDS_STACK][grid threads]; the thread's column is worked out on use (rare)
+    uint32_t ovf_stride;
     int sp;
+    RT_DEV uint2 *deep(int slot) const {
+        return ovf + ((size_t)(slot - RT_LDS_STACK) * ovf_stride + (blockIdx.x * blockDim.x + threadIdx.x));
+    }
     RT_DEV void store(int slot, uint32_t w, float t) {
         if (slot < RT_LDS_STACK)
             lds[slot * lds_stride] = make_uint2(w, __float_as_uint(t));
         else
-            ovf[(size_t)(slot - RT_LDS_STACK) * ovf_stride] = make_uint2(w, __float_as_uint(t));
+            *deep(slot) = make_uint2(w, __float_as_uint(t));
     }
     RT_DEV void pop(uint32_t *w, float *t) {
         sp--;
-        uint2 e = (sp < RT_LDS_STACK) ? lds[sp * lds_stride] : ovf[(size_t)(sp - RT_LDS_STACK) * ovf_stride];
+        uint2 e = (sp < RT_LDS_STACK) ? lds[sp * lds_stride] : *deep(sp);
         *w = e.x;
         *t = __uint_as_float(e.y);
     }

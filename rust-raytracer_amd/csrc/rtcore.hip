@@ -114,12 +114,11 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     __shared__ uint2 s_stack[RT_LDS_STACK * kBlock];
     const uint32_t n = count_ptr ? *count_ptr : n_fixed;
     const uint32_t lane = threadIdx.x & 63u;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
     Stack st;
     st.lds = s_stack + threadIdx.x;
     st.lds_stride = kBlock;
-    st.ovf = ovf + (blockIdx.x * blockDim.x + threadIdx.x);
-    st.ovf_stride = (size_t)gridDim.x * blockDim.x;
+    st.ovf = ovf;
+    st.ovf_stride = gridDim.x * blockDim.x;
     st.sp = 0;
     uint32_t visits = 0, tests = 0;
     unsigned long long dbg[6] = {0, 0, 0, 0, 0, 0};  // leaf steps, lanes in them, node steps, lanes in them, lanes without a ray over all steps, refills (lane 0 of each wave)
@@ -159,7 +158,9 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
                 const uint32_t avail = chunk_end - chunk_next;
                 const uint32_t give = want < avail ? want : avail;
                 if (ray_i < 0) {
-                    const uint32_t rank = (uint32_t)__popcll(empty_mask & lanes_below);
+                    // empty lanes below this one
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(empty_mask >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)empty_mask, 0u));
                     if (rank < give) {
                         const uint32_t i = chunk_next + rank;
                         float4 o4 = ro[i], d4 = rd[i];
