@@ -269,6 +269,88 @@ struct Collapser {
         return RT_CHILD_LEAF | ((count - 1) << 28) | first;
     }
 
+    // Which binary nodes become roots of wide nodes.  A ray opens a wide node about as often as it
+    // hits the root's box, so the cost of a collapse is taken as the sum of the half areas of the
+    // wide nodes' root boxes (leaf slots are the same in every collapse), and the cheapest
+    // collapse follows from a bottom-up table over the binary tree:
+    //   dist(b, j)  the cheapest way to hand the two subtrees of b to at most j slots of one wide node
+    //   root(b)     half_area(b) + dist(b, 4): b roots a wide node of its own
+    // where a subtree given k slots is either one slot that roots its own wide node or is dissolved
+    // further into at most k slots.
+    std::vector<float> root_cost;
+    std::vector<float> dist[3];      // [j - 2][node]
+    std::vector<uint8_t> to_left[3]; // slots that go to the left child in dist(b, j)
+    bool optimal = false;
+
+    float subtree_cost(int32_t c, int k) const {  // subtree c in at most k slots
+        if (c < 0 || terminal(c)) return 0.0f;
+        float best = root_cost[c];
+        for (int j = 2; j <= k; j++) best = std::min(best, dist[j - 2][c]);
+        return best;
+    }
+    void plan(int32_t root) {
+        const size_t n = bn.size();
+        root_cost.assign(n, 0.0f);
+        for (int j = 0; j < 3; j++) dist[j].assign(n, 0.0f), to_left[j].assign(n, 1);
+        std::vector<int32_t> order;
+        order.reserve(n);
+        std::vector<int32_t> stack{root};
+        while (!stack.empty()) {
+            int32_t b = stack.back();
+            stack.pop_back();
+            if (terminal(b)) continue;
+            order.push_back(b);
+            if (bn[b].left != kNone && bn[b].left >= 0) stack.push_back(bn[b].left);
+            if (bn[b].right != kNone && bn[b].right >= 0) stack.push_back(bn[b].right);
+        }
+        for (size_t i = order.size(); i-- > 0;) {  // children before parents
+            const int32_t b = order[i], l = bn[b].left, r = bn[b].right;
+            for (int j = 2; j <= 4; j++) {
+                float best;
+                int best_k;
+                if (l == kNone || r == kNone) {
+                    best_k = (l == kNone) ? 0 : j;
+                    best = subtree_cost(l == kNone ? r : l, j);
+                } else {
+                    best = INFINITY, best_k = 1;
+                    for (int k = 1; k < j; k++) {
+                        float v = subtree_cost(l, k) + subtree_cost(r, j - k);
+                        if (v < best) best = v, best_k = k;
+                    }
+                }
+                dist[j - 2][b] = best;
+                to_left[j - 2][b] = (uint8_t)best_k;
+            }
+            root_cost[b] = half_area(bn[b].box) + dist[2][b];
+        }
+        optimal = true;
+    }
+    // the slots of the wide node that dissolves b into at most j slots, by the table
+    void gather(int32_t b, int j, Slot *slots, int &n) const {
+        const int k = to_left[j - 2][b];
+        place(b, bn[b].left, k, slots, n);
+        place(b, bn[b].right, j - k, slots, n);
+    }
+    void place(int32_t parent, int32_t c, int k, Slot *slots, int &n) const {
+        if (c == kNone || k <= 0) return;
+        if (c < 0) {
+            slots[n++] = Slot{bn[parent].box, c};  // a bare leaf is tested under its parent's box
+            return;
+        }
+        if (terminal(c)) {
+            slots[n++] = Slot{bn[c].box, c};
+            return;
+        }
+        float best = root_cost[c];
+        int best_j = 1;
+        for (int j = 2; j <= k; j++)
+            if (dist[j - 2][c] < best) best = dist[j - 2][c], best_j = j;
+        if (best_j == 1)
+            slots[n++] = Slot{bn[c].box, c};
+        else
+            gather(c, best_j, slots, n);
+    }
+
     uint32_t make(int32_t b, uint32_t depth) {
         if (depth > depth_max) depth_max = depth;
         Slot slots[4];
@@ -276,6 +358,9 @@ struct Collapser {
         if (terminal(b)) {
             slots[0] = Slot{bn[b].box, b};
             n = 1;
+        } else if (optimal) {
+            n = 0;
+            gather(b, 4, slots, n);
         } else {
             n = child_slots(b, slots);
             for (;;) {
@@ -801,6 +886,9 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
         const char *interior = std::getenv("RTCORE_INTERIOR");
         if (!(interior && std::strcmp(interior, "sah") == 0)) {
             Collapser C(B.nodes, rank_of, hs.nodes);
+            // RTCORE_COLLAPSE=greedy keeps the simpler rule (dissolve the child with the largest box first)
+            const char *collapse = std::getenv("RTCORE_COLLAPSE");
+            if (!(collapse && std::strcmp(collapse, "greedy") == 0)) C.plan(root);
             C.make(root, 1);
             if (C.overflow) {
                 err = "internal: leaf encoding overflow";
