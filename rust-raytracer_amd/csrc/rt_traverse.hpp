@@ -35,13 +35,13 @@ struct Best {
     bool ties;      // does the best primitive's own bound check accept t == t_max
 };
 
-RT_DEV void consider(Best &b, float t, bool ties, int32_t index) {
-    bool closer = (t < b.t) || (t == b.t && ((index > b.index) ? ties : !b.ties));
-    if (closer) {
-        b.t = t;
-        b.index = index;
-        b.ties = ties;
-    }
+// `valid` = the primitive's own test passed; written without branches (the lanes of a wave test
+// different primitives, so an early exit never lets the wave skip anything)
+RT_DEV void consider(Best &b, bool valid, float t, bool ties, int32_t index) {
+    bool closer = valid && ((t < b.t) || (t == b.t && ((index > b.index) ? ties : !b.ties)));
+    b.t = closer ? t : b.t;
+    b.index = closer ? index : b.index;
+    b.ties = closer ? ties : b.ties;
 }
 
 // ABox::hit without the normal (src/tracer/cube.rs:42-56): candidate t and whether it is the entry face
@@ -104,19 +104,20 @@ RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, cons
     if (type == RT_PRIM_TRIANGLE) {
         // Triangle::hit (src/tracer/triangle.rs:37-66); e1, e2 are stored, they are the same floats
         F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
+        // the reference's early returns, as one predicate over the same expressions
         F3 h = cross(ray.d, e2);
         float a = dot(e1, h);
-        if ((!flag && (__float_as_uint(a) >> 31)) || fabsf(a) < 1e-6f) return;
+        bool ok = !((!flag && (__float_as_uint(a) >> 31)) || fabsf(a) < 1e-6f);
         float f = 1.0f / a;
         F3 s = ray.o - v0;
         float u = f * dot(s, h);
-        if (!(u >= 0.0f && u <= 1.0f)) return;
+        ok = ok && (u >= 0.0f && u <= 1.0f);
         F3 q = cross(s, e1);
         float v = f * dot(ray.d, q);
-        if (v < 0.0f || u + v > 1.0f) return;
+        ok = ok && !(v < 0.0f || u + v > 1.0f);
         float t = f * dot(e2, q);
-        if (t < t_min || t > t_max) return;
-        consider(best, t, true, index);
+        ok = ok && !(t < t_min || t > t_max);
+        consider(best, ok, t, true, index);
     } else if (type == RT_PRIM_SPHERE) {
         // Sphere::hit (src/tracer/sphere.rs:28-58)
         F3 c = f3(r0.x, r0.y, r0.z);
@@ -128,17 +129,17 @@ RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, cons
             float h = sqrtf(disc);
             float temp = -half_b - h;
             if (temp < t_max && temp > t_min) {
-                consider(best, temp, false, index);
+                consider(best, true, temp, false, index);
                 return;
             }
             temp = -half_b + h;
-            if (temp < t_max && temp > t_min) consider(best, temp, false, index);
+            if (temp < t_max && temp > t_min) consider(best, true, temp, false, index);
         }
     } else if (type == RT_PRIM_ABOX) {
         F3 lo = f3(r0.x, r0.y, r0.z), hi = f3(r0.w, r1.x, r1.y);
         float t;
         bool entry;
-        if (abox_candidate(lo, hi, ray, inv, t_min, t_max, &t, &entry)) consider(best, t, entry, index);
+        if (abox_candidate(lo, hi, ray, inv, t_min, t_max, &t, &entry)) consider(best, true, t, entry, index);
     } else {
         F3 center = f3(r0.x, r0.y, r0.z), half = f3(r0.w, r1.x, r1.y);
         Rotor rot{r1.z, r1.w, r2.x, r2.y};
@@ -147,7 +148,7 @@ RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, cons
         bool entry;
         F3 linv = f3(1.0f / local.d.x, 1.0f / local.d.y, 1.0f / local.d.z);
         if (abox_candidate(center - half, center + half, local, linv, t_min, t_max, &t, &entry))
-            consider(best, t, entry, index);
+            consider(best, true, t, entry, index);
     }
 }
 
