@@ -93,11 +93,9 @@ RT_DEV Ray cube_local_ray(F3 center, Rotor rot, const Ray &ray) {
     return l;
 }
 
-// Tests the primitive at `index` and offers its candidate to `best`.  t_max is the ray's own bound.
-RT_DEV void test_primitive(const float4 *__restrict__ prims, int32_t index, const Ray &ray, F3 inv, float t_min,
-                           float t_max, Best &best) {
-    const float4 *r = prims + (size_t)index * RT_PRIM_FLOAT4S;
-    float4 r0 = r[0], r1 = r[1], r2 = r[2];
+// Tests the primitive whose record is (r0, r1, r2) and offers its candidate to `best`.  t_max is the ray's own bound.
+RT_DEV void test_record(float4 r0, float4 r1, float4 r2, int32_t index, const Ray &ray, F3 inv, float t_min,
+                        float t_max, Best &best) {
     uint32_t meta = __float_as_uint(r2.z);
     uint32_t type = meta & RT_PRIM_TYPE_MASK;
     bool flag = (meta & RT_PRIM_FLAG) != 0;
@@ -164,7 +162,7 @@ RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, const Best &best, 
     *prim_id = (int32_t)__float_as_uint(r2.w);
     if (type == RT_PRIM_TRIANGLE) {
         // The traversal carries only (t, rank): the barycentrics of the winning triangle are worked
-        // out again here, by the same operations on the same floats as in test_primitive, so they
+        // out again here, by the same operations on the same floats as in test_record, so they
         // are the same bits (src/tracer/triangle.rs:41-58).
         F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
         F3 h = cross(ray.d, e2);
@@ -278,9 +276,19 @@ RT_DEV bool traversal_leaf_step(const RtSceneView &sc, Traversal &tr, Stack &st,
     const uint32_t entry = tr.entry;
     int32_t first = (int32_t)(entry & RT_LEAF_FIRST_MASK);
     int32_t count = (int32_t)((entry >> 28) & 7u) + 1;
-    for (int32_t k = 0; k < count; k++) {
-        if (COUNT) (*tests)++;
-        test_primitive(prims, first + k, tr.ray, tr.inv, t_min, t_max, tr.best);
+    // A leaf holds one or two primitives (more only if a builder packs them): both records are
+    // fetched before the first test so that their latencies overlap.
+    const float4 *r = prims + (size_t)first * RT_PRIM_FLOAT4S;
+    const bool two = count > 1;
+    float4 a0 = r[0], a1 = r[1], a2 = r[2];
+    float4 b0 = a0, b1 = a1, b2 = a2;
+    if (two) b0 = r[3], b1 = r[4], b2 = r[5];
+    if (COUNT) (*tests) += (uint32_t)count;
+    test_record(a0, a1, a2, first, tr.ray, tr.inv, t_min, t_max, tr.best);
+    if (two) test_record(b0, b1, b2, first + 1, tr.ray, tr.inv, t_min, t_max, tr.best);
+    for (int32_t k = 2; k < count; k++) {
+        const float4 *q = prims + (size_t)(first + k) * RT_PRIM_FLOAT4S;
+        test_record(q[0], q[1], q[2], first + k, tr.ray, tr.inv, t_min, t_max, tr.best);
     }
     return traversal_pop(tr, st);
 }
