@@ -253,10 +253,15 @@ RT_DEV bool traversal_begin(const RtSceneView &sc, Traversal &tr, Stack &st, flo
     return tn <= tf;
 }
 
-// Next entry from the stack; an entry whose box starts beyond the best hit is dropped.
-// Returns true when the stack has run empty: the traversal is finished.
-RT_DEV bool traversal_pop(Traversal &tr, Stack &st) {
-    while (st.sp > 0) {
+// One turn of taking the next entry from the stack; an entry whose box starts beyond the best hit
+// is dropped (and the lane still wants an entry).  Sets `finished` when the stack has run empty.
+// Returns true while the lane still wants an entry.
+RT_DEV bool traversal_pop_turn(Traversal &tr, Stack &st, bool &finished) {
+    if (st.sp <= 0) {
+        finished = true;
+        return false;
+    }
+    if (st.sp > RT_LDS_STACK) {  // the top entry is in the overflow area
         uint32_t w;
         float t;
         st.pop(&w, &t);
@@ -264,14 +269,28 @@ RT_DEV bool traversal_pop(Traversal &tr, Stack &st) {
             tr.entry = w;
             return false;
         }
+        return true;
     }
+    // the two top entries in one LDS round trip
+    const int below = st.sp >= 2 ? st.sp - 2 : 0;
+    const uint2 e1 = st.lds[(st.sp - 1) * st.lds_stride], e2 = st.lds[below * st.lds_stride];
+    if (__uint_as_float(e1.y) <= tr.best.t) {
+        tr.entry = e1.x;
+        st.sp -= 1;
+        return false;
+    }
+    if (st.sp >= 2 && __uint_as_float(e2.y) <= tr.best.t) {
+        tr.entry = e2.x;
+        st.sp -= 2;
+        return false;
+    }
+    st.sp = below;
     return true;
 }
 
-// tr.entry is a leaf: tests its primitives, then pops.  Returns true when the traversal is finished.
+// tr.entry is a leaf: tests its primitives.  The lane then wants the next stack entry.
 template <bool COUNT>
-RT_DEV bool traversal_leaf_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, float t_max,
-                                uint32_t *tests) {
+RT_DEV void traversal_leaf_step(const RtSceneView &sc, Traversal &tr, float t_min, float t_max, uint32_t *tests) {
     const float4 *__restrict__ prims = (const float4 *)sc.prims;
     const uint32_t entry = tr.entry;
     int32_t first = (int32_t)(entry & RT_LEAF_FIRST_MASK);
@@ -290,11 +309,10 @@ RT_DEV bool traversal_leaf_step(const RtSceneView &sc, Traversal &tr, Stack &st,
         const float4 *q = prims + (size_t)(first + k) * RT_PRIM_FLOAT4S;
         test_record(q[0], q[1], q[2], first + k, tr.ray, tr.inv, t_min, t_max, tr.best);
     }
-    return traversal_pop(tr, st);
 }
 
-// tr.entry is a node: tests its four child boxes, pushes the far hits, continues with the
-// nearest (or pops).  Returns true when the traversal is finished.
+// tr.entry is a node: tests its four child boxes, pushes the far hits and continues with the
+// nearest.  Returns true when no child was hit: the lane then wants the next stack entry.
 template <bool COUNT>
 RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
     const char *__restrict__ nodes = (const char *)sc.nodes;
@@ -368,11 +386,8 @@ RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st,
         }
         st.sp = top;
     }
-    if (nh > 0) {
-        tr.entry = cw[0];
-        return false;
-    }
-    return traversal_pop(tr, st);
+    if (nh > 0) tr.entry = cw[0];
+    return nh == 0;
 }
 
 }  // namespace rtd

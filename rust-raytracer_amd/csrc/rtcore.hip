@@ -103,6 +103,10 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
 #endif
 constexpr uint32_t kVoteEnough = RT_VOTE_ENOUGH;
 constexpr uint32_t kVoteFew = RT_VOTE_FEW;
+#ifndef RT_POP_TURNS
+#define RT_POP_TURNS 1
+#endif
+constexpr int kPopTurns = RT_POP_TURNS;
 constexpr uint32_t kRayChunk = RT_RAY_CHUNK;
 constexpr uint32_t kServiceLanes = RT_SERVICE_LANES;
 
@@ -125,6 +129,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     Traversal tr;
     int32_t ray_i = -1;     // ray this lane works on, -1 = none
     bool parked = false;    // traversal finished, result not yet written
+    bool popping = false;   // wants the next entry of its stack
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: the reserved run of ray indices
     bool no_more = false;                    // wave-uniform: the global counter ran past n
 
@@ -178,12 +183,12 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         }
         // One step for part of the wave: lanes at a node and lanes at a leaf need different code,
         // so each iteration runs only the kind that more lanes are waiting for; the others wait.
-        const bool active = ray_i >= 0 && !parked;
+        const bool active = ray_i >= 0 && !parked && !popping;
         const bool at_leaf = active && (tr.entry & RT_CHILD_LEAF) != 0u;
         const bool at_node = active && !at_leaf;
         const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
         const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
-        if (n_leaf + n_node == 0u) {
+        if (n_leaf + n_node == 0u && __ballot(popping) == 0ull) {
             if (no_more && __ballot(parked) == 0ull) break;
             continue;
         }
@@ -197,8 +202,19 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
             if (run_node && n_node) dbg[2]++, dbg[3] += n_node;
             dbg[4] += 64u - n_leaf - n_node;
         }
-        if (run_leaf && at_leaf) parked = traversal_leaf_step<COUNT>(sc, tr, st, t_min, t_max, &tests);
-        if (run_node && at_node) parked = traversal_node_step<COUNT>(sc, tr, st, t_min, &visits);
+        if (run_leaf && at_leaf) {
+            traversal_leaf_step<COUNT>(sc, tr, t_min, t_max, &tests);
+            popping = true;
+        }
+        if (run_node && at_node) popping = traversal_node_step<COUNT>(sc, tr, st, t_min, &visits);
+        // Next entry for the lanes that want one.  After a hit most of a ray's stack is beyond the
+        // best distance and is dropped entry by entry; a wave waits for its slowest lane (an unbounded
+        // loop here took 5.1 turns per leaf step and 1.5 per node step), so each step is followed by
+        // kPopTurns turns of two entries each, and a lane with a longer run of dead entries goes on
+        // with it on the wave's next turns (it takes no part in the steps meanwhile).
+#pragma unroll
+        for (int turn = 0; turn < kPopTurns; turn++)
+            if (popping) popping = traversal_pop_turn(tr, st, parked);
     }
     if (COUNT) {
         atomicAdd(&counters[0], (unsigned long long)visits);
@@ -841,7 +857,7 @@ int rt_scene_stats(const RtScene *cs, RtStats *out) {
         s->stats.prim_tests += c[1];
         if (std::getenv("RTCORE_DEBUG_STEPS") && c[2] + c[4])
             std::fprintf(stderr,
-                         "[rtcore] leaf steps %llu with %.1f lanes, node steps %llu with %.1f lanes, %.1f lanes without a ray "
+                         "[rtcore] leaf steps %llu with %.1f lanes, node steps %llu with %.1f lanes, %.1f lanes not stepping "
                          "per step, %llu refills\n",
                          c[2], c[2] ? (double)c[3] / (double)c[2] : 0.0, c[4], c[4] ? (double)c[5] / (double)c[4] : 0.0,
                          (double)c[6] / (double)(c[2] + c[4]), c[7]);
