@@ -90,19 +90,19 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
 #define RT_RAY_CHUNK 256
 #endif
 #ifndef RT_SERVICE_LANES
-#define RT_SERVICE_LANES 24
+#define RT_SERVICE_LANES 40
 #endif
 #ifndef RT_EXTEND_WAVES
 #define RT_EXTEND_WAVES 7
 #endif
-#ifndef RT_VOTE_ENOUGH
-#define RT_VOTE_ENOUGH 65
+#ifndef RT_VOTE_LEAF_WEIGHT
+#define RT_VOTE_LEAF_WEIGHT 3
 #endif
-#ifndef RT_VOTE_FEW
-#define RT_VOTE_FEW 0
+#ifndef RT_VOTE_NODE_WEIGHT
+#define RT_VOTE_NODE_WEIGHT 2
 #endif
-constexpr uint32_t kVoteEnough = RT_VOTE_ENOUGH;
-constexpr uint32_t kVoteFew = RT_VOTE_FEW;
+constexpr uint32_t kVoteLeafWeight = RT_VOTE_LEAF_WEIGHT;
+constexpr uint32_t kVoteNodeWeight = RT_VOTE_NODE_WEIGHT;
 #ifndef RT_POP_TURNS
 #define RT_POP_TURNS 1
 #endif
@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     st.ovf_stride = gridDim.x * blockDim.x;
     st.sp = 0;
     uint32_t visits = 0, tests = 0;
-    unsigned long long dbg[6] = {0, 0, 0, 0, 0, 0};  // leaf steps, lanes in them, node steps, lanes in them, lanes without a ray over all steps, refills (lane 0 of each wave)
+    unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // leaf steps, lanes in them, node steps, lanes in them, lanes without a ray over all steps, refills (lane 0 of each wave)
     Traversal tr;
     int32_t ray_i = -1;     // ray this lane works on, -1 = none
     bool parked = false;    // traversal finished, result not yet written
@@ -133,12 +133,14 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: the reserved run of ray indices
     bool no_more = false;                    // wave-uniform: the global counter ran past n
 
+    const long long loop_t0 = COUNT ? clock64() : 0;
     for (;;) {
         const unsigned long long parked_mask = __ballot(parked);
         const unsigned long long idle_mask = __ballot(parked || ray_i < 0);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
         if (n_idle >= kServiceLanes && (parked_mask != 0ull || !no_more)) {
             if (COUNT && lane == 0) dbg[5]++;
+            const long long svc_t0 = COUNT ? clock64() : 0;
             if (parked) {
                 hit[ray_i] = make_float2(tr.best.t, __int_as_float(tr.best.index));
                 parked = false;
@@ -180,6 +182,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
                 }
                 chunk_next += give;
             }
+            if (COUNT && lane == 0) dbg[6] += (unsigned long long)(clock64() - svc_t0);
         }
         // One step for part of the wave: lanes at a node and lanes at a leaf need different code,
         // so each iteration runs only the kind that more lanes are waiting for; the others wait.
@@ -192,11 +195,9 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
             if (no_more && __ballot(parked) == 0ull) break;
             continue;
         }
-        // A kind runs when it is the majority, when it has enough lanes to be worth its issue
-        // slots anyway, or when so few lanes are active that latency, not issue, is the cost.
-        const bool few = n_leaf + n_node <= kVoteFew;
-        const bool run_leaf = n_leaf >= n_node || n_leaf >= kVoteEnough || few;
-        const bool run_node = n_node > n_leaf || n_node >= kVoteEnough || few;
+        // The kind with the (weighted) majority runs.
+        const bool run_leaf = n_leaf * kVoteLeafWeight >= n_node * kVoteNodeWeight;
+        const bool run_node = !run_leaf;
         if (COUNT && lane == 0) {  // occupancy of the two step kinds, for tuning
             if (run_leaf && n_leaf) dbg[0]++, dbg[1] += n_leaf;
             if (run_node && n_node) dbg[2]++, dbg[3] += n_node;
@@ -220,7 +221,10 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         atomicAdd(&counters[0], (unsigned long long)visits);
         atomicAdd(&counters[1], (unsigned long long)tests);
         if (lane == 0)
-            for (int k = 0; k < 6; k++) atomicAdd(&counters[2 + k], dbg[k]);
+        {
+            dbg[7] = (unsigned long long)(clock64() - loop_t0);
+            for (int k = 0; k < 8; k++) atomicAdd(&counters[2 + k], dbg[k]);
+        }
     }
 }
 
@@ -529,8 +533,8 @@ int ensure_work(RtScene *s, uint64_t paths) {
         RT_HIP(hipMemset(s->totals.p, 0, 64));
     }
     if (!s->counters.p) {
-        if ((rc = s->counters.ensure(64))) return rc;
-        RT_HIP(hipMemset(s->counters.p, 0, 64));
+        if ((rc = s->counters.ensure(128))) return rc;
+        RT_HIP(hipMemset(s->counters.p, 0, 128));
     }
     {   // persistent waves: launch what is resident at once
         int per_cu = 0;
@@ -851,7 +855,7 @@ int rt_scene_stats(const RtScene *cs, RtStats *out) {
         RT_HIP(hipMemset(s->totals.p, 0, 64));
     }
     if (s->counters.p) {
-        unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         RT_HIP(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         s->stats.node_visits += c[0];
         s->stats.prim_tests += c[1];
@@ -860,8 +864,10 @@ int rt_scene_stats(const RtScene *cs, RtStats *out) {
                          "[rtcore] leaf steps %llu with %.1f lanes, node steps %llu with %.1f lanes, %.1f lanes not stepping "
                          "per step, %llu refills\n",
                          c[2], c[2] ? (double)c[3] / (double)c[2] : 0.0, c[4], c[4] ? (double)c[5] / (double)c[4] : 0.0,
-                         (double)c[6] / (double)(c[2] + c[4]), c[7]);
-        RT_HIP(hipMemset(s->counters.p, 0, 64));
+                         (double)c[6] / (double)(c[2] + c[4]), c[7]),
+            std::fprintf(stderr, "[rtcore] refills take %.1f %% of the waves' time, %.0f clocks each\n",
+                         100.0 * (double)c[8] / (double)(c[9] ? c[9] : 1), (double)c[8] / (double)(c[7] ? c[7] : 1));
+        RT_HIP(hipMemset(s->counters.p, 0, 128));
     }
     *out = s->stats;
     s->stats = RtStats{};
