@@ -248,7 +248,7 @@ def main():
 def measured_traffic(args, info):
     """HBM bytes per closest-hit launch from the PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE in its
     own run, summarised by tools/extend_pmc_json.py), or None when no profile of this configuration is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_extend_pmc_c4_default.json")
+    path = os.path.join(ROOT, "profiles", "r01_extend_pmc_c4_final.json")
     default_cfg = (args.workload == "mesh" and args.tris == 10_000_000 and (args.width, args.height) == (3840, 2160)
                    and args.spp == 16 and args.bounces == 8 and args.batch_paths == 0)
     if not (default_cfg and os.path.exists(path)):
