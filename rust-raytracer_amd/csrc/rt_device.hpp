@@ -254,61 +254,63 @@ RT_DEV F3 ray_at(const Ray &r, float t) { return r.o + t * r.d; }
 
 // Material::scatter (src/material.rs:176-183 -> :28-35, :44-59, :67-81, :96-136).
 // Returns the attenuation; new_dir is the scattered direction before Ray::new normalises it.
+//
+// The lanes of a wave hold different materials, and a wave runs every branch one of its lanes takes, so
+// the work the models have in common is written once: the cosine-weighted direction (Lambertian,
+// Glossy), the normal jittered by a point of the unit ball (Glossy, Metal, Dielectric; the three draws
+// differ per model), the mirror direction and the Fresnel term.  Each lane still evaluates exactly its
+// model's expressions on its model's arguments.
 RT_DEV F3 scatter(const RtDevMaterial &m, const Ray &ray, float t, F3 normal, uint32_t key, uint32_t bounce,
                   F3 *new_dir) {
-    float r1 = draw(key, bounce, DIM_R1), r2 = draw(key, bounce, DIM_R2);
-    F3 albedo = f3(m.albedo[0], m.albedo[1], m.albedo[2]);
-    if (m.type == RT_MAT_LAMBERTIAN) {
-        *new_dir = on_hemisphere(normal, r1, r2);
+    const float r1 = draw(key, bounce, DIM_R1), r2 = draw(key, bounce, DIM_R2);
+    const F3 albedo = f3(m.albedo[0], m.albedo[1], m.albedo[2]);
+    const bool lambertian = m.type == RT_MAT_LAMBERTIAN, glossy = m.type == RT_MAT_GLOSSY;
+    const bool metal = m.type == RT_MAT_METAL, dielectric = !(lambertian || glossy || metal);
+    F3 diffuse_dir = f3(0.0f, 0.0f, 0.0f);
+    if (lambertian || glossy) diffuse_dir = on_hemisphere(normal, r1, r2);
+    if (lambertian) {
+        *new_dir = diffuse_dir;
         return albedo;
     }
-    if (m.type == RT_MAT_GLOSSY) {
-        float reflectance = m.p0, roughness = m.p1;
-        F3 rnd = in_unit_sphere(draw(key, bounce, DIM_S0), draw(key, bounce, DIM_S1), draw(key, bounce, DIM_S2));
-        F3 jn = normalized(normal + (rnd * roughness));
-        float cosine = dot(-ray.d, jn);
-        float prob = schlick(cosine, kAirIndex, 1.0f + reflectance);
-        if (draw(key, bounce, DIM_CHOICE) <= prob) {
-            *new_dir = reflected(ray.d, jn);
-            return f3(1.0f, 1.0f, 1.0f) * 0.9f;
+    // Glossy / Metal: in_unit_sphere() draws three numbers (src/material.rs:46,69); Dielectric: the
+    // caller's r1, r2 and one more (src/material.rs:98-99)
+    const float s0 = draw(key, bounce, DIM_S0), s1 = draw(key, bounce, DIM_S1), s2 = draw(key, bounce, DIM_S2);
+    const F3 rnd = in_unit_sphere(dielectric ? r1 : s0, dielectric ? r2 : s1, dielectric ? s0 : s2);
+    const float roughness = metal ? m.p0 : m.p1;
+    const F3 jn = normalized(normal + (rnd * roughness));
+    F3 outward = jn, color = f3(1.0f, 1.0f, 1.0f) * 0.9f;
+    float ni = kAirIndex, nt, cosine;
+    bool total_reflection = false;
+    if (dielectric) {
+        const float ior = m.p0;
+        if (dot(ray.d, normal) > 0.0f) {
+            F3 absorbance = albedo * -t * 2.0f;
+            outward = -jn;
+            ni = ior;
+            nt = kAirIndex;
+            cosine = dot(ray.d, jn);
+            color = f3(det_exp(absorbance.x), det_exp(absorbance.y), det_exp(absorbance.z));
+        } else {
+            nt = ior;
+            cosine = dot(-ray.d, jn);
         }
-        *new_dir = on_hemisphere(normal, r1, r2);
-        return albedo;
+        total_reflection = !((ni / nt) * sqrtf(1.0f - (cosine * cosine)) <= 1.0f);
+    } else {
+        nt = 1.0f + m.p0;  // Glossy: 1 + reflectance; unused by Metal
+        cosine = dot(-ray.d, jn);
     }
-    if (m.type == RT_MAT_METAL) {
-        float roughness = m.p0;
-        F3 rnd = in_unit_sphere(draw(key, bounce, DIM_S0), draw(key, bounce, DIM_S1), draw(key, bounce, DIM_S2));
-        F3 jn = normalized(normal + (rnd * roughness));
-        *new_dir = reflected(ray.d, jn);
-        float cosine = dot(-ray.d, jn);
+    const F3 mirrored = reflected(ray.d, outward);
+    if (metal) {
+        *new_dir = mirrored;
         return clamped(albedo + (f3(1.0f, 1.0f, 1.0f) - albedo) * powi5(1.0f - cosine), 0.0f, 1.0f);
     }
-    // dielectric
-    float ior = m.p0, roughness = m.p1;
-    F3 rnd = in_unit_sphere(r1, r2, draw(key, bounce, DIM_S0));
-    F3 jn = normalized(normal + (rnd * roughness));
-    F3 outward, color;
-    float ni, nt, cosine;
-    if (dot(ray.d, normal) > 0.0f) {
-        F3 absorbance = albedo * -t * 2.0f;
-        outward = -jn;
-        ni = ior;
-        nt = kAirIndex;
-        cosine = dot(ray.d, jn);
-        color = f3(det_exp(absorbance.x), det_exp(absorbance.y), det_exp(absorbance.z));
-    } else {
-        outward = jn;
-        ni = kAirIndex;
-        nt = ior;
-        cosine = dot(-ray.d, jn);
-        color = f3(1.0f, 1.0f, 1.0f) * 0.9f;
+    const float prob = schlick(cosine, ni, nt);
+    const bool specular = total_reflection || draw(key, bounce, DIM_CHOICE) <= prob;
+    if (glossy) {
+        *new_dir = specular ? mirrored : diffuse_dir;
+        return specular ? color : albedo;
     }
-    if ((ni / nt) * sqrtf(1.0f - (cosine * cosine)) <= 1.0f) {
-        float prob = schlick(cosine, ni, nt);
-        *new_dir = (draw(key, bounce, DIM_CHOICE) <= prob) ? reflected(ray.d, outward) : refracted(ray.d, outward, ni / nt);
-    } else {
-        *new_dir = reflected(ray.d, outward);
-    }
+    *new_dir = specular ? mirrored : refracted(ray.d, outward, ni / nt);
     return color;
 }
 

@@ -233,7 +233,10 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
 // and every lane takes base + (live lanes of earlier waves) + (live lanes below it in its wave).
 // A single global counter sustains only about 90 atomics per microsecond, so per-wave atomics
 // would cap a 4K pass at that rate.  Must be called by every thread of the block.
-constexpr int kShadeBlock = 1024;
+#ifndef RT_SHADE_BLOCK
+#define RT_SHADE_BLOCK 512
+#endif
+constexpr int kShadeBlock = RT_SHADE_BLOCK;
 __device__ __forceinline__ uint32_t block_compact_slot(bool alive, uint32_t *counter, uint32_t *s_counts) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     const unsigned long long mask = __ballot(alive);
