@@ -37,6 +37,10 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kCountSlots = 1024;  // live-path counts [0, kCountSlots), extend work counters [kCountSlots, 2 kCountSlots)
+#ifndef RT_TILE_ROWS
+#define RT_TILE_ROWS 8
+#endif
+constexpr uint32_t kTileRows = RT_TILE_ROWS;
 constexpr float kTMin = 0.00015f;   // src/render.rs:15
 constexpr float kTMax = 100000.0f;  // src/render.rs:16
 
@@ -62,7 +66,16 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
     }
     if (i >= n) return;
     uint32_t s = i / np, j = i - s * np;
-    uint32_t pixel = p0 + j;
+    // Consecutive paths take the pixels of 8-row strips column by column (a permutation of the batch's
+    // pixel offsets), so the 64 lanes of a wave start on an 8 x 8 tile of the frame rather than on a
+    // 64 x 1 line: their rays meet the same nodes.  The radiance slot stays `sample * np + offset`.
+    uint32_t off = j;
+    const uint32_t strip = kTileRows * width, whole = np / strip * strip;
+    if (j < whole) {
+        const uint32_t b = j / strip, r = j - b * strip;
+        off = (b * kTileRows + r % kTileRows) * width + r / kTileRows;
+    }
+    uint32_t pixel = p0 + off;
     float x = (float)(pixel % width);
     float y = (float)(height - 1 - pixel / width);
     float jx, jy;
@@ -71,7 +84,7 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
     F3 org, dir;
     gen_ray(cam, width, height, x, y, jx, jy, &org, &dir);
     dir = normalized(dir);  // Ray::new (src/ray.rs:10-15)
-    out.o[i] = make_float4(org.x, org.y, org.z, __uint_as_float(i));
+    out.o[i] = make_float4(org.x, org.y, org.z, __uint_as_float(s * np + off));
     out.d[i] = make_float4(dir.x, dir.y, dir.z, 0.0f);
     out.thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(key));
 }
