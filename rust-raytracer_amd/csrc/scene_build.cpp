@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -913,6 +914,22 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
             hs.wide_depth = C.depth_max;
         }
         hs.n_nodes = hs.nodes.size() / 32;
+        if (std::getenv("RTCORE_DEBUG_TREE")) {  // surface-area cost of the wide tree, for comparing builders
+            double inner = 0.0, leaf = 0.0;
+            for (size_t nd = 0; nd < hs.nodes.size() / 32; nd++) {
+                const float *f = &hs.nodes[nd * 32];
+                uint32_t w[4];
+                std::memcpy(w, f + 24, 16);
+                for (int c = 0; c < 4; c++) {
+                    if (w[c] == RT_CHILD_NONE) continue;
+                    double dx = f[12 + c] - f[c], dy = f[16 + c] - f[4 + c], dz = f[20 + c] - f[8 + c];
+                    double a = dx * dy + dy * dz + dz * dx;
+                    if (w[c] & RT_CHILD_LEAF) leaf += a; else inner += a;
+                }
+            }
+            std::fprintf(stderr, "[rtcore] wide tree: %zu nodes, summed half area of node children %.6g, of leaf children %.6g\n",
+                         hs.nodes.size() / 32, inner, leaf);
+        }
         if (hs.n_nodes >= (1ull << 25)) {  // kernels address nodes with 32-bit byte offsets
             err = "too many tree nodes";
             return RT_ERR_INVALID_ARGUMENT;
