@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
 // A single global counter sustains only about 90 atomics per microsecond, so per-wave atomics
 // would cap a 4K pass at that rate.  Must be called by every thread of the block.
 #ifndef RT_SHADE_BLOCK
-#define RT_SHADE_BLOCK 512
+#define RT_SHADE_BLOCK 1024
 #endif
 constexpr int kShadeBlock = RT_SHADE_BLOCK;
 __device__ __forceinline__ uint32_t block_compact_slot(bool alive, uint32_t *counter, uint32_t *s_counts) {
