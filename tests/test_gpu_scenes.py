@@ -126,3 +126,22 @@ def test_rtrender_end_to_end(tmp_path, pkg):
     px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, 1 + 3 * W)[:, 1:].reshape(H * W, 3).astype(np.uint32)
     got = (255 << 24) | (px[:, 0] << 16) | (px[:, 1] << 8) | px[:, 2]
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_answers_do_not_depend_on_the_wide_tree(pkg, oracle, monkeypatch):
+    """The interior of the wide tree is free (which binary nodes root wide nodes, or a rebuilt interior): every
+    variant must return the reference's primitive and distance for every ray."""
+    d = pkg.scenes.mesh_scene(n_triangles=60_000, rings=32, segments=32, seed=11)
+    ora = oracle.OracleScene(d)
+    rays = pkg.scenes.random_rays(400_000, *ora.bounds(), seed=5)
+    want_ids, want_t, _, _ = ora.closest_hit(rays)
+    for name, value in (("RTCORE_COLLAPSE", "greedy"), ("RTCORE_INTERIOR", "sah"), (None, None)):
+        if name:
+            monkeypatch.setenv(name, value)
+        scene = pkg.Scene(d)
+        if name:
+            monkeypatch.delenv(name)
+        ids, t, _, _ = scene.closest_hit(rays)
+        assert np.array_equal(ids, want_ids), name
+        assert np.array_equal(t.view(np.uint32), want_t.view(np.uint32)), name
