@@ -153,7 +153,7 @@ RT_DEV void test_record(float4 r0, float4 r1, float4 r2, int32_t index, const Ra
 // HitRecord fields of the winning primitive: normal, material, primitive id.
 RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, const Best &best, F3 *normal, uint32_t *material,
                        int32_t *prim_id) {
-    const float4 *r = (const float4 *)sc.prims + (size_t)best.index * RT_PRIM_FLOAT4S;
+    const float4 *r = (const float4 *)sc.shade_records + (size_t)best.index * (2 * RT_PRIM_FLOAT4S);
     float4 r0 = r[0], r1 = r[1], r2 = r[2];
     uint32_t meta = __float_as_uint(r2.z);
     uint32_t type = meta & RT_PRIM_TYPE_MASK;
@@ -171,7 +171,7 @@ RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, const Best &best, 
         float u = f * dot(s, h);
         float v = f * dot(ray.d, cross(s, e1));
         // src/tracer/triangle.rs:68-70
-        const float4 *nn = (const float4 *)sc.tri_normals + (size_t)best.index * 3;
+        const float4 *nn = r + RT_PRIM_FLOAT4S;
         float4 a = nn[0], b = nn[1], c = nn[2];
         F3 n0 = f3(a.x, a.y, a.z), n1 = f3(b.x, b.y, b.z), n2 = f3(c.x, c.y, c.z);
         *normal = normalized((1.0f - (u + v)) * n0 + u * n1 + v * n2);

@@ -78,7 +78,8 @@ struct RtDevCamera {
 struct RtSceneView {
     const void *nodes;       // float4[n_nodes * 8]
     const void *prims;       // float4[n_prims * 3]
-    const void *tri_normals; // float4[n_prims * 3]
+    const void *shade_records; // float4[n_prims * 6]: the primitive's record and its three vertex normals side by side,
+                               // one 96-byte gather for the stage that completes a hit
     const void *materials;   // RtDevMaterial[n_materials]
     const float *env;        // rgb float triples or nullptr
     uint32_t env_w, env_h;

@@ -772,13 +772,13 @@ int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
     };
     if ((rc = upload(s->nodes, h.nodes.data(), h.nodes.size() * 4))) return rc;
     if ((rc = upload(s->prims, h.prims.data(), h.prims.size() * 4))) return rc;
-    if ((rc = upload(s->normals, h.tri_normals.data(), h.tri_normals.size() * 4))) return rc;
+    if ((rc = upload(s->normals, h.shade_records.data(), h.shade_records.size() * 4))) return rc;
     if ((rc = upload(s->materials, h.materials.data(), h.materials.size() * sizeof(RtDevMaterial)))) return rc;
     if ((rc = upload(s->env, h.env.data(), h.env.size() * 4))) return rc;
     RtSceneView &v = s->view;
     v.nodes = s->nodes.p;
     v.prims = s->prims.p;
-    v.tri_normals = s->normals.p;
+    v.shade_records = s->normals.p;
     v.materials = s->materials.p;
     v.env = (const float *)s->env.p;
     v.env_w = h.env_w;
@@ -790,7 +790,7 @@ int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
     // the device copies are what the kernels read; drop the host arrays
     std::vector<float>().swap(h.nodes);
     std::vector<uint32_t>().swap(h.prims);
-    std::vector<float>().swap(h.tri_normals);
+    std::vector<float>().swap(h.shade_records);
     std::vector<float>().swap(h.env);
     *out = s.release();
     return RT_OK;
@@ -810,7 +810,7 @@ int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info) {
     info->wide_depth = h.wide_depth;
     info->node_bytes = RT_NODE_FLOAT4S * 16;
     info->primitive_bytes = RT_PRIM_FLOAT4S * 16;
-    info->device_bytes = (h.nodes.size() + h.prims.size() + h.tri_normals.size() + h.env.size()) * 4 +
+    info->device_bytes = (h.nodes.size() + h.prims.size() + h.shade_records.size() + h.env.size()) * 4 +
                          h.materials.size() * sizeof(RtDevMaterial);
     for (int k = 0; k < 3; k++) info->bounds_min[k] = h.root_lo[k], info->bounds_max[k] = h.root_hi[k];
     return RT_OK;

@@ -939,11 +939,12 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
 
         // ---- records in rank order
         hs.prims.assign(total * 12, 0);
-        hs.tri_normals.assign(total * 12, 0.0f);
+        hs.shade_records.assign(total * 24, 0.0f);
         for (uint64_t p = 0; p < total; p++) {
             uint64_t r = rank_of[p];
             std::memcpy(&hs.prims[r * 12], &rec[p * 12], 48);
-            std::memcpy(&hs.tri_normals[r * 12], &nrm[p * 12], 48);
+            std::memcpy(&hs.shade_records[r * 24], &rec[p * 12], 48);
+            std::memcpy(&hs.shade_records[r * 24 + 12], &nrm[p * 12], 48);
         }
     }
     hs.n_prims = total;

@@ -16,7 +16,7 @@ namespace rtcore {
 struct HostScene {
     std::vector<float> nodes;          // 32 floats per wide node
     std::vector<uint32_t> prims;       // 12 words per primitive, visit-rank order
-    std::vector<float> tri_normals;    // 12 floats per primitive (zero for non-triangles)
+    std::vector<float> shade_records;  // 24 floats per primitive: its record again, then three vertex normals (zero for non-triangles)
     std::vector<RtDevMaterial> materials;
     std::vector<float> env;
     uint32_t env_w = 0, env_h = 0;
