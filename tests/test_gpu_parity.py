@@ -238,3 +238,25 @@ def test_render_pass_rejects_bad_parameters(pkg):
         acc = np.zeros(W * H * 3, np.float32)
         with pytest.raises(pkg.RtError):
             scene.render_pass(acc, pkg.Scene.params(W, H, spp, 8))
+
+
+def test_deep_stacks_spill_to_the_overflow_area(pkg, oracle):
+    """2000 large overlapping spheres and boxes in a small volume: a ray through the middle hits most child boxes at
+    every level, so the per-lane stack outgrows its LDS part and uses the overflow area in HBM."""
+    rng = np.random.default_rng(3)
+    S = pkg.SceneDescription()
+    m = S.add_material(pkg.lambertian((0.5, 0.5, 0.5)))
+    for i in range(2000):
+        c = rng.normal(0.0, 1.0, 3)
+        if i % 2:
+            S.add_sphere(tuple(c), float(0.5 + 2.0 * rng.random()), m)
+        else:
+            S.add_axis_box(tuple(c), tuple(1.0 + 3.0 * rng.random(3)), m)
+    scene = pkg.Scene(S)
+    assert scene.info().wide_depth * 3 + 4 > 11  # deeper than the LDS part of the stack
+    n = 20000
+    o = rng.normal(0.0, 4.0, (n, 3))
+    d = -o + rng.normal(0.0, 0.3, (n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d], axis=1).astype(np.float32)
+    check_hits(pkg, oracle, S, rays, 0.00015, 100000.0)
