@@ -273,68 +273,112 @@ __device__ __forceinline__ uint32_t block_compact_slot(bool alive, uint32_t *cou
 // ---------------------------------------------------------------------------
 // shade: the body of ray_color's loop (src/render.rs:62-81) for bounce `bounce`
 // ---------------------------------------------------------------------------
+// Two flags per thread, one reservation per block.
+__device__ __forceinline__ void block_compact_slots2(bool alive0, bool alive1, uint32_t *counter, uint32_t *s_counts,
+                                                     uint32_t *dst0, uint32_t *dst1) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const unsigned long long m0 = __ballot(alive0), m1 = __ballot(alive1);
+    if (lane == 0) s_counts[wave] = (uint32_t)(__popcll(m0) + __popcll(m1));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (uint32_t w = 0; w < n_waves; w++) {
+            uint32_t c = s_counts[w];
+            s_counts[w] = total;
+            total += c;
+        }
+        s_counts[n_waves] = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t base = s_counts[n_waves] + s_counts[wave];
+    *dst0 = base + (uint32_t)__popcll(m0 & below);
+    *dst1 = base + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1 & below);
+    __syncthreads();  // s_counts is reused by the next call
+}
+
+// One path of shade_kernel: returns whether the path goes on; if so (new_o, new_d, thr) is its next state,
+// otherwise its radiance sample has been stored.
+__device__ __forceinline__ bool shade_path(const RtSceneView &sc, const RtDevMaterial *mats, const PathState &in,
+                                           const float2 *__restrict__ hit_a, float4 *__restrict__ rad, uint32_t i,
+                                           uint32_t bounce, uint32_t depth, float light_clamp, F3 *new_o, F3 *new_d,
+                                           F3 *thr_out, float *slot_bits, float *key_bits) {
+    const float4 o4 = in.o[i], d4 = in.d[i], th4 = in.thr[i];
+    const float2 ha = hit_a[i];
+    const uint32_t slot = __float_as_uint(o4.w);
+    const uint32_t key = __float_as_uint(th4.w);
+    *slot_bits = o4.w;
+    *key_bits = th4.w;
+    Ray ray;
+    ray.o = f3(o4.x, o4.y, o4.z);
+    ray.d = f3(d4.x, d4.y, d4.z);
+    F3 thr = f3(th4.x, th4.y, th4.z);
+    F3 result;
+    bool alive = false;
+    if (__float_as_int(ha.y) >= 0) {
+        Best best{ha.x, __float_as_int(ha.y), false};
+        F3 nrm;
+        uint32_t mat;
+        int32_t pid;
+        finish_hit(sc, ray, best, &nrm, &mat, &pid);
+        RtDevMaterial m = mats[mat];
+        F3 sdir;
+        F3 att = scatter(m, ray, ha.x, nrm, key, bounce, &sdir);
+        if (max3(att) <= 1.0f) {
+            thr = thr * att;
+            if (max3(thr) < draw(key, bounce, DIM_RR)) {
+                result = thr * 0.01f;  // Russian-roulette break, src/render.rs:68-70,83
+            } else {
+                thr = thr * (1.0f / max3(thr));
+                if (bounce + 1 == depth) {
+                    result = thr * 0.01f;  // depth exhausted, src/render.rs:83
+                } else {
+                    alive = true;
+                    *new_o = ray_at(ray, ha.x);
+                    *new_d = normalized(sdir);
+                }
+            }
+        } else {
+            result = thr * clamped(att, 0.0f, 1.0f * light_clamp);  // emitter, src/render.rs:73-77
+        }
+    } else {
+        result = thr * get_sky(sc, ray.d, light_clamp);  // src/render.rs:80
+    }
+    if (!alive) rad[slot] = make_float4(result.x, result.y, result.z, 0.0f);
+    *thr_out = thr;
+    return alive;
+}
+
 __global__ void __launch_bounds__(kShadeBlock)
     shade_kernel(RtSceneView sc, PathState in, const float2 *__restrict__ hit_a,
                  const uint32_t *__restrict__ count_in, PathState out, uint32_t *count_out, float4 *__restrict__ rad,
                  uint32_t bounce, uint32_t depth, float light_clamp) {
     __shared__ uint32_t s_counts[kShadeBlock / 64 + 1];
     const uint32_t n = *count_in;
-    const uint32_t stride = gridDim.x * blockDim.x;
     const RtDevMaterial *mats = (const RtDevMaterial *)sc.materials;
-    // every thread of a block runs the same number of iterations: the compaction has barriers
-    const uint32_t n_round = (n + (uint32_t)kShadeBlock - 1u) / (uint32_t)kShadeBlock * (uint32_t)kShadeBlock;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
-        bool alive = false;
-        float4 o4, d4, th4;
-        F3 new_o, new_d, thr;
-        if (i < n) {
-            o4 = in.o[i];
-            d4 = in.d[i];
-            th4 = in.thr[i];
-            float2 ha = hit_a[i];
-            uint32_t slot = __float_as_uint(o4.w);
-            uint32_t key = __float_as_uint(th4.w);
-            Ray ray;
-            ray.o = f3(o4.x, o4.y, o4.z);
-            ray.d = f3(d4.x, d4.y, d4.z);
-            thr = f3(th4.x, th4.y, th4.z);
-            F3 result;
-            if (__float_as_int(ha.y) >= 0) {
-                Best best{ha.x, __float_as_int(ha.y), false};
-                F3 nrm;
-                uint32_t mat;
-                int32_t pid;
-                finish_hit(sc, ray, best, &nrm, &mat, &pid);
-                RtDevMaterial m = mats[mat];
-                F3 sdir;
-                F3 att = scatter(m, ray, ha.x, nrm, key, bounce, &sdir);
-                if (max3(att) <= 1.0f) {
-                    thr = thr * att;
-                    if (max3(thr) < draw(key, bounce, DIM_RR)) {
-                        result = thr * 0.01f;  // Russian-roulette break, src/render.rs:68-70,83
-                    } else {
-                        thr = thr * (1.0f / max3(thr));
-                        if (bounce + 1 == depth) {
-                            result = thr * 0.01f;  // depth exhausted, src/render.rs:83
-                        } else {
-                            alive = true;
-                            new_o = ray_at(ray, ha.x);
-                            new_d = normalized(sdir);
-                        }
-                    }
-                } else {
-                    result = thr * clamped(att, 0.0f, 1.0f * light_clamp);  // emitter, src/render.rs:73-77
-                }
-            } else {
-                result = thr * get_sky(sc, ray.d, light_clamp);  // src/render.rs:80
-            }
-            if (!alive) rad[slot] = make_float4(result.x, result.y, result.z, 0.0f);
+    // A block takes runs of 2 * kShadeBlock paths, two per thread, and reserves their places in the output
+    // queue with ONE atomic (the queue counter sustains only about 90 atomics per microsecond).  Every thread of
+    // a block runs the same number of turns: the compaction has barriers.
+    const uint32_t run = 2u * (uint32_t)kShadeBlock;
+    const uint32_t n_runs = (n + run - 1u) / run;
+    for (uint32_t r = blockIdx.x; r < n_runs; r += gridDim.x) {
+        const uint32_t i0 = r * run + threadIdx.x, i1 = i0 + (uint32_t)kShadeBlock;
+        bool alive0 = false, alive1 = false;
+        F3 o0, d0, t0, o1, d1, t1;
+        float slot0 = 0.0f, key0 = 0.0f, slot1 = 0.0f, key1 = 0.0f;
+        if (i0 < n) alive0 = shade_path(sc, mats, in, hit_a, rad, i0, bounce, depth, light_clamp, &o0, &d0, &t0, &slot0, &key0);
+        if (i1 < n) alive1 = shade_path(sc, mats, in, hit_a, rad, i1, bounce, depth, light_clamp, &o1, &d1, &t1, &slot1, &key1);
+        uint32_t dst0, dst1;
+        block_compact_slots2(alive0, alive1, count_out, s_counts, &dst0, &dst1);
+        if (alive0) {
+            out.o[dst0] = make_float4(o0.x, o0.y, o0.z, slot0);
+            out.d[dst0] = make_float4(d0.x, d0.y, d0.z, 0.0f);
+            out.thr[dst0] = make_float4(t0.x, t0.y, t0.z, key0);
         }
-        uint32_t dst = block_compact_slot(alive, count_out, s_counts);
-        if (alive) {
-            out.o[dst] = make_float4(new_o.x, new_o.y, new_o.z, o4.w);
-            out.d[dst] = make_float4(new_d.x, new_d.y, new_d.z, 0.0f);
-            out.thr[dst] = make_float4(thr.x, thr.y, thr.z, th4.w);
+        if (alive1) {
+            out.o[dst1] = make_float4(o1.x, o1.y, o1.z, slot1);
+            out.d[dst1] = make_float4(d1.x, d1.y, d1.z, 0.0f);
+            out.thr[dst1] = make_float4(t1.x, t1.y, t1.z, key1);
         }
     }
 }
@@ -690,7 +734,7 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
                                    (const float2 *)s->hit_a.p, counts + b, rad,
                                    preview && p->mode == RT_MODE_IMAGE ? (int)RT_MODE_IMAGE : (int)p->mode);
             } else {
-                uint32_t sblocks = std::min((n + kShadeBlock - 1) / kShadeBlock, (uint32_t)s->n_cus * 4u);
+                uint32_t sblocks = std::min((n + 2 * kShadeBlock - 1) / (2 * kShadeBlock), (uint32_t)s->n_cus * 4u);
                 hipLaunchKernelGGL(shade_kernel, dim3(sblocks), dim3(kShadeBlock), 0, stream, s->view, st[cur],
                                    (const float2 *)s->hit_a.p, counts + b, st[cur ^ 1],
                                    counts + b + 1, rad, b, depth, p->light_clamp);
