@@ -1,4 +1,4 @@
-"""Full-size runs (the sizes BASELINE.json names) checked through properties that do not need a full CPU render:
+"""Full-size runs (the sizes the headline configurations are quoted on) checked through properties that do not need a full CPU render:
 rows of a 4K pass spot-checked bit for bit by the oracle, counters that must add up, and the 100 M-ray
 closest-hit batch checked on an oracle subsample plus run-to-run and chunking invariance of its id checksum."""
 import zlib

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condenses a tools/profile_extend.sh directory into one JSON: per-launch figures of the closest-hit
-kernel (uninstrumented launches only) for bench.py's roofline.traffic and for DESIGN.md.
+kernel (uninstrumented launches only) for bench.py's roofline.traffic.
 FETCH_SIZE is in KiB of fabric read requests tallied at 64 B; on gfx950 a wide (16 B per lane) read
 stream reports half of its bytes, so `hbm_bytes_corrected` doubles it.  That factor is calibrated for
 coalesced streams, not for this kernel's one-line-per-lane gathers; both figures are given."""
