@@ -300,7 +300,8 @@ RT_DEV void traversal_leaf_step(const RtSceneView &sc, Traversal &tr, float t_mi
     const float4 *r = prims + (size_t)first * RT_PRIM_FLOAT4S;
     const bool two = count > 1;
     float4 a0 = r[0], a1 = r[1], a2 = r[2];
-    float4 b0 = a0, b1 = a1, b2 = a2;
+    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // (not a copy of the first record: that would wait for it)
+    float4 b0 = zero, b1 = zero, b2 = zero;
     if (two) b0 = r[3], b1 = r[4], b2 = r[5];
     if (COUNT) (*tests) += (uint32_t)count;
     test_record(a0, a1, a2, first, tr.ray, tr.inv, t_min, t_max, tr.best);
