@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -652,7 +653,29 @@ void make_camera(const RtCamera &c, float aspect, RtDevCamera &o) {
     o.v[0] = v.x, o.v[1] = v.y, o.v[2] = v.z;
 }
 
+// fn(lo, hi) over [0, n) on up to 16 host threads (one when n is small)
+template <class F>
+void parallel_ranges(uint64_t n, F fn) {
+    unsigned hw = std::thread::hardware_concurrency();
+    uint64_t parts = std::min<uint64_t>(std::min<unsigned>(hw ? hw : 1u, 16u), n / 65536u);
+    if (parts <= 1) {
+        fn((uint64_t)0, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (uint64_t k = 0; k < parts; k++)
+        pool.emplace_back([=, &fn]() { fn(n * k / parts, n * (k + 1) / parts); });
+    for (auto &t : pool) t.join();
+}
+
 int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
+    const bool debug_tree = std::getenv("RTCORE_DEBUG_TREE") != nullptr;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char *name) {  // RTCORE_DEBUG_TREE=1: where the build time goes
+        auto now = std::chrono::steady_clock::now();
+        if (debug_tree) std::fprintf(stderr, "[rtcore] build: %-28s %.3f s\n", name, std::chrono::duration<double>(now - t_phase).count());
+        t_phase = now;
+    };
     if (!d || (d->n_objects && !d->objects) || (d->n_materials && !d->materials) || (d->n_meshes && !d->meshes)) {
         err = "null scene description";
         return RT_ERR_INVALID_ARGUMENT;
@@ -705,6 +728,7 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
         return RT_ERR_INVALID_ARGUMENT;
     }
 
+    phase("checks");
     // ---- primitives in declaration order
     std::vector<uint32_t> rec(total * 12, 0);
     std::vector<float> nrm(total * 12, 0.0f);
@@ -804,16 +828,18 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
                 Rotor rot = rotor_from_euler(m.rotation[2], m.rotation[0], m.rotation[1]);
                 V3 sc = v3(m.scale[0], m.scale[1], m.scale[2]);
                 V3 tr = v3(m.translation[0], m.translation[1], m.translation[2]);
-                for (uint64_t f = 0; f < m.n_faces; f++) {
-                    V3 vv[3], nn[3];
-                    for (int k = 0; k < 3; k++) {
-                        uint64_t vi = m.indices[3 * f + k];
-                        V3 p = v3(m.positions[3 * vi], m.positions[3 * vi + 1], m.positions[3 * vi + 2]);
-                        vv[k] = add(rotate(rot, mul(p, sc)), tr);
-                        nn[k] = rotate(rot, v3(m.normals[3 * vi], m.normals[3 * vi + 1], m.normals[3 * vi + 2]));
+                parallel_ranges(m.n_faces, [&](uint64_t f_lo, uint64_t f_hi) {
+                    for (uint64_t f = f_lo; f < f_hi; f++) {
+                        V3 vv[3], nn[3];
+                        for (int k = 0; k < 3; k++) {
+                            uint64_t vi = m.indices[3 * f + k];
+                            V3 p = v3(m.positions[3 * vi], m.positions[3 * vi + 1], m.positions[3 * vi + 2]);
+                            vv[k] = add(rotate(rot, mul(p, sc)), tr);
+                            nn[k] = rotate(rot, v3(m.normals[3 * vi], m.normals[3 * vi + 1], m.normals[3 * vi + 2]));
+                        }
+                        tri(id + f, vv, nn, !m.cull_backface);
                     }
-                    tri(id + f, vv, nn, !m.cull_backface);
-                }
+                });
                 mesh_spans.push_back(MeshSpan{id, m.n_faces});
                 mesh_world_slot.push_back(world_items.size());
                 world_items.push_back(Item{kNone, Box{}});  // filled once the mesh tree exists
@@ -824,6 +850,7 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
         }
     }
 
+    phase("primitive records and boxes");
     // ---- binary trees
     Builder B;
     B.nodes.resize(2 * (total + world_items.size()) + 2);  // a run of n items makes at most 2n - 1 nodes
@@ -854,6 +881,7 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
         hs.n_binary_nodes = (uint64_t)B.next_node.load();
         B.nodes.resize(hs.n_binary_nodes);
 
+        phase("binary trees (sort + split)");
         // ---- visit ranks: right child first
         std::vector<uint32_t> rank_of(total, 0);
         {
@@ -877,6 +905,7 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
             }
         }
 
+        phase("visit ranks");
         // ---- wide nodes
         hs.nodes.clear();
         hs.nodes.reserve((total / 4 + 8) * 32);
@@ -937,16 +966,20 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
         hs.max_stack = 3 * hs.wide_depth + 4;
         for (int k = 0; k < 3; k++) hs.root_lo[k] = B.nodes[root].box.lo[k], hs.root_hi[k] = B.nodes[root].box.hi[k];
 
+        phase("wide nodes");
         // ---- records in rank order
         hs.prims.assign(total * 12, 0);
         hs.shade_records.assign(total * 24, 0.0f);
-        for (uint64_t p = 0; p < total; p++) {
-            uint64_t r = rank_of[p];
-            std::memcpy(&hs.prims[r * 12], &rec[p * 12], 48);
-            std::memcpy(&hs.shade_records[r * 24], &rec[p * 12], 48);
-            std::memcpy(&hs.shade_records[r * 24 + 12], &nrm[p * 12], 48);
-        }
+        parallel_ranges(total, [&](uint64_t p_lo, uint64_t p_hi) {
+            for (uint64_t p = p_lo; p < p_hi; p++) {
+                uint64_t r = rank_of[p];
+                std::memcpy(&hs.prims[r * 12], &rec[p * 12], 48);
+                std::memcpy(&hs.shade_records[r * 24], &rec[p * 12], 48);
+                std::memcpy(&hs.shade_records[r * 24 + 12], &nrm[p * 12], 48);
+            }
+        });
     }
+    phase("records in rank order");
     hs.n_prims = total;
 
     hs.materials.resize(d->n_materials);
