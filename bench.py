@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+LIMITER = None  # what the PMC profile says bounds the kernel, when one is committed for the configuration
 
 
 def build_workload(pkg, args):
@@ -225,6 +226,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "traffic_note": traffic_note,
+                "limiter": LIMITER,
                 "launches": launches,
                 "mean_launch_ms": round(st.extend_ms / launches, 3),
                 "algorithmic_bytes_per_launch": int(st.rays * bytes_per_ray / launches),
@@ -254,6 +256,10 @@ def measured_traffic(args, info):
     if not (default_cfg and os.path.exists(path)):
         return None, "no PMC profile committed for this configuration"
     p = json.load(open(path))
+    global LIMITER
+    LIMITER = ("instruction issue, not bandwidth: VALU busy %.0f %% of SIMD cycles at %.0f %% active lanes, L2 hit rate %.0f %% "
+               "(same PMC profile); algorithmic bytes exceed HBM traffic because the upper tree levels are served from cache"
+               % (100 * p["valu_busy_fraction"], 100 * p["valu_lane_utilisation"], 100 * p["l2_hit_rate"]))
     return (int(p["hbm_bytes_per_launch_corrected"]),
             "bytes per launch from %s: FETCH_SIZE x 1 KiB x 2 (gfx950 reports half the bytes of 16 B/lane reads; "
             "calibrated on coalesced streams, this kernel gathers one line per lane); raw %d" % (
