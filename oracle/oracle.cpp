@@ -1160,7 +1160,10 @@ uint32_t oracle_to_rgb(const float rgb[3], float gamma) {
     Vec3 b = v * (0.983729f * v + (splat(1.0f) * 0.432951f)) + (splat(1.0f) * 0.238081f);
     Vec3 q = a / b;
     Vec3 o = (m2c0 * q.x + m2c1 * q.y + m2c2 * q.z).clamped(splat(0.0f), splat(1.0f));
-    o = Vec3(std::pow(o.x, gamma), std::pow(o.y, gamma), std::pow(o.z, gamma));
+    // f32::powf; evaluated in double and rounded once, which is what a correctly rounded powf returns except on
+    // near-ties of the double result (the product does the same, so the packed pixels can be compared exactly)
+    o = Vec3((float)std::pow((double)o.x, (double)gamma), (float)std::pow((double)o.y, (double)gamma),
+             (float)std::pow((double)o.z, (double)gamma));
     return (255u << 24) | ((uint32_t)(o.x * 255.4f) << 16) | ((uint32_t)(o.y * 255.4f) << 8) |
            ((uint32_t)(o.z * 255.4f));
 }

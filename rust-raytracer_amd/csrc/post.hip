@@ -35,7 +35,9 @@ __global__ void __launch_bounds__(kBlock)
     uint32_t out = 255u << 24;
     for (int k = 0; k < 3; k++) {
         float c = fminf(fmaxf(o[k], 0.0f), 1.0f);  // clamped: NaN -> 0
-        c = powf(c, inv_gamma);
+        // f32::powf of the reference, taken through double precision: the device's and the host's single-precision
+        // pow differ in the last bit now and then, their double-precision ones round to the same float
+        c = (float)pow((double)c, (double)inv_gamma);
         float s = c * 255.4f;
         uint32_t u = (s != s || s <= 0.0f) ? 0u : (uint32_t)s;  // `as u32` saturates, NaN -> 0
         out |= u << (16 - 8 * k);

@@ -1033,7 +1033,7 @@ uint32_t rt_to_rgb(const float rgb[3], float inv_gamma) {
     for (int k = 0; k < 3; k++) {
         o[k] = m2[0][k] * q[0] + m2[1][k] * q[1] + m2[2][k] * q[2];
         o[k] = std::fmin(std::fmax(o[k], 0.0f), 1.0f);
-        o[k] = std::pow(o[k], inv_gamma);
+        o[k] = (float)std::pow((double)o[k], (double)inv_gamma);  // as the device kernel does (see post.hip)
         out |= ((uint32_t)(o[k] * 255.4f)) << (16 - 8 * k);
     }
     return out;

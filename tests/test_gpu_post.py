@@ -22,14 +22,9 @@ def test_tonemap_device_matches_to_rgb(pkg, oracle):
     pkg.render.tonemap_device(d_rgb.data_ptr(), n, divisor, gamma, d_out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     got = d_out.cpu().numpy().view(np.uint32)
-    # powf on the device and in libm may differ in the last bit, which can move a channel across an integer
-    # boundary of c * 255.4: at most one level, on a tiny share of pixels
-    ch = lambda a, s: ((a >> s) & 255).astype(np.int32)
+    # both sides take the power through double precision, so the packed pixels agree exactly
     finite = np.isfinite(rgb).all(axis=1)
-    for s in (16, 8, 0):
-        d = np.abs(ch(got, s) - ch(want, s))[finite]
-        assert d.max() <= 1
-        assert (d != 0).mean() < 2e-3
+    assert np.array_equal(got[finite], want[finite])
     assert np.all((got >> 24) == 255)
     # the known answers of the host function hold on the device too (divisor 4 folded in)
     assert got[1004] == want[1004] and got[1005] == want[1005] and got[1006] == want[1006]
