@@ -1179,7 +1179,8 @@ void oracle_to_rgb_array(const float *rgb, size_t n, float divisor, float gamma,
 // arithmetic is the wrapping u32 arithmetic of the reference's release build.
 void oracle_bilateral_filter(const float *img, float *out, uint32_t w, uint32_t h, uint32_t diameter, float sigma_i,
                              float sigma_s) {
-    auto gaussian = [](float x, float sigma) { return std::exp(-(x * x) / (2.0f * sigma * sigma)) / (2.0f * PI * sigma * sigma); };
+    // f32::exp as the deterministic polynomial the rest of the restatement uses (the product's kernel uses the same)
+    auto gaussian = [](float x, float sigma) { return detm::exp(-(x * x) / (2.0f * sigma * sigma)) / (2.0f * PI * sigma * sigma); };
     const uint32_t half = diameter / 2;
     for (uint32_t cur = 0; cur < w * h; cur++) {
         uint32_t x = cur % w, y = cur / w;

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "../../include/rtcore.h"
+#include "rt_device.hpp"
 
 namespace {
 
@@ -47,7 +48,8 @@ __global__ void __launch_bounds__(kBlock)
 
 __device__ __forceinline__ float gaussian(float x, float sigma) {
     const float kPi = 3.14159265358979323846f;
-    return expf(-(x * x) / (2.0f * sigma * sigma)) / (2.0f * kPi * sigma * sigma);
+    // the same exp polynomial as the path tracer's (and the oracle's), so the filtered frame can be compared exactly
+    return rtd::det_exp(-(x * x) / (2.0f * sigma * sigma)) / (2.0f * kPi * sigma * sigma);
 }
 
 __global__ void __launch_bounds__(kBlock)
