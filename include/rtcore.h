@@ -260,6 +260,11 @@ int rt_tonemap_device(const float *d_rgb, size_t n_pixels, float divisor, float 
                       void *stream);
 int rt_bilateral_filter_device(const float *d_in, float *d_out, uint32_t width, uint32_t height, uint32_t diameter,
                                float sigma_i, float sigma_s, void *stream);
+/* The same on host buffers (copied over PCIe, synchronous), for a host that keeps its frame in a Vec<Vec3>
+ * as src/main.rs does. */
+int rt_tonemap(const float *rgb, size_t n_pixels, float divisor, float inv_gamma, uint32_t *argb);
+int rt_bilateral_filter(const float *in, float *out, uint32_t width, uint32_t height, uint32_t diameter,
+                        float sigma_i, float sigma_s);
 
 /*
  * Host-side helpers that need no device: the reference's display transform,

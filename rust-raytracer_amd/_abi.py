@@ -158,6 +158,8 @@ SYMBOLS = {
     "rt_set_counting": (C.c_int, [_VP, C.c_int]),
     "rt_tonemap_device": (C.c_int, [_VP, C.c_size_t, C.c_float, C.c_float, _VP, _VP]),
     "rt_bilateral_filter_device": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, _VP]),
+    "rt_tonemap": (C.c_int, [_VP, C.c_size_t, C.c_float, C.c_float, _VP]),
+    "rt_bilateral_filter": (C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float]),
     "rt_to_rgb": (C.c_uint32, [_FP, C.c_float]),
 }
 

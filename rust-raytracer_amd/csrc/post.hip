@@ -113,4 +113,45 @@ int rt_bilateral_filter_device(const float *d_in, float *d_out, uint32_t width, 
     return RT_OK;
 }
 
+// Host-buffer variants: copy in, run the kernels above on the current device, copy out, synchronise.
+int rt_tonemap(const float *rgb, size_t n_pixels, float divisor, float inv_gamma, uint32_t *argb) {
+    if (!rgb || !argb) return rt_set_error_message(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_pixels == 0) return RT_OK;
+    float *d_in = nullptr;
+    uint32_t *d_out = nullptr;
+    int rc = RT_OK;
+    hipError_t e = hipMalloc((void **)&d_in, n_pixels * 12);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n_pixels * 4);
+    if (e != hipSuccess) rc = rt_set_error_message(e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE, hipGetErrorString(e));
+    if (rc == RT_OK && (e = hipMemcpy(d_in, rgb, n_pixels * 12, hipMemcpyHostToDevice)) != hipSuccess)
+        rc = rt_set_error_message(RT_ERR_DEVICE, hipGetErrorString(e));
+    if (rc == RT_OK) rc = rt_tonemap_device(d_in, n_pixels, divisor, inv_gamma, d_out, nullptr);
+    if (rc == RT_OK && (e = hipMemcpy(argb, d_out, n_pixels * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = rt_set_error_message(RT_ERR_DEVICE, hipGetErrorString(e));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
+int rt_bilateral_filter(const float *in, float *out, uint32_t width, uint32_t height, uint32_t diameter, float sigma_i,
+                        float sigma_s) {
+    if (!in || !out || in == out) return rt_set_error_message(RT_ERR_INVALID_ARGUMENT, "null or aliased buffers");
+    if (width == 0 || height == 0 || (uint64_t)width * height > 0x7fffffffull)
+        return rt_set_error_message(RT_ERR_INVALID_ARGUMENT, "bad frame size");
+    const size_t bytes = (size_t)width * height * 12;
+    float *d_in = nullptr, *d_out = nullptr;
+    int rc = RT_OK;
+    hipError_t e = hipMalloc((void **)&d_in, bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_out, bytes);
+    if (e != hipSuccess) rc = rt_set_error_message(e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE, hipGetErrorString(e));
+    if (rc == RT_OK && (e = hipMemcpy(d_in, in, bytes, hipMemcpyHostToDevice)) != hipSuccess)
+        rc = rt_set_error_message(RT_ERR_DEVICE, hipGetErrorString(e));
+    if (rc == RT_OK) rc = rt_bilateral_filter_device(d_in, d_out, width, height, diameter, sigma_i, sigma_s, nullptr);
+    if (rc == RT_OK && (e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost)) != hipSuccess)
+        rc = rt_set_error_message(RT_ERR_DEVICE, hipGetErrorString(e));
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return rc;
+}
+
 }  // extern "C"

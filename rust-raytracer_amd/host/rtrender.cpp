@@ -189,15 +189,22 @@ int main(int argc, char **argv) {
         for (float &v : buffer) v = v / (float)passes_done;
     }
     if (args.filter) {  // src/main.rs:114-132
-        std::vector<float> tmp;
+        std::vector<float> tmp(buffer.size());
         for (uint32_t i = 1; i < 4; i++) {
-            imageio::bilateral_filter(buffer, tmp, args.width, args.height, 9 / i, 0.05f / (float)i, 1.0f / (float)i);
+            if (rt_bilateral_filter(buffer.data(), tmp.data(), args.width, args.height, 9 / i, 0.05f / (float)i,
+                                    1.0f / (float)i) != RT_OK) {
+                std::fprintf(stderr, "filter failed: %s\n", rt_last_error());
+                return 1;
+            }
             buffer.swap(tmp);
         }
     }
     std::vector<uint32_t> final_img(n_px);
     const float inv_gamma = 1.0f / args.gamma;
-    for (size_t i = 0; i < n_px; i++) final_img[i] = rt_to_rgb(&buffer[3 * i], inv_gamma);
+    if (rt_tonemap(buffer.data(), n_px, 1.0f, inv_gamma, final_img.data()) != RT_OK) {
+        std::fprintf(stderr, "tonemap failed: %s\n", rt_last_error());
+        return 1;
+    }
     std::string out = args.out;
     if (out.empty()) {
         auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();

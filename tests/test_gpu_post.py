@@ -57,3 +57,22 @@ def test_post_argument_errors(pkg):
     lib = pkg.load()
     assert lib.rt_tonemap_device(None, 10, 1.0, 1.0, None, None) == pkg._abi.RT_ERR_INVALID_ARGUMENT
     assert lib.rt_bilateral_filter_device(None, None, 4, 4, 3, 0.1, 1.0, None) == pkg._abi.RT_ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_host_buffer_variants_equal_the_device_ones(pkg, oracle):
+    lib = pkg.load()
+    rng = np.random.default_rng(9)
+    W, H = 64, 40
+    img = (rng.random((H * W, 3)) * 0.3 + 0.2).astype(np.float32)
+    out = np.empty_like(img)
+    want = np.empty_like(img)
+    pkg._abi.check(lib.rt_bilateral_filter(img.ctypes.data, out.ctypes.data, W, H, 9, 0.05, 1.0))
+    oracle.lib().oracle_bilateral_filter(img.ctypes.data, want.ctypes.data, W, H, 9, 0.05, 1.0)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+    packed = np.empty(H * W, np.uint32)
+    wanted = np.empty(H * W, np.uint32)
+    pkg._abi.check(lib.rt_tonemap(out.ctypes.data, H * W, 2.0, 1.0 / 2.2, packed.ctypes.data))
+    oracle.lib().oracle_to_rgb_array(want.ctypes.data, H * W, 2.0, 1.0 / 2.2, wanted.ctypes.data)
+    assert np.array_equal(packed, wanted)
+    assert lib.rt_bilateral_filter(img.ctypes.data, img.ctypes.data, W, H, 9, 0.05, 1.0) == pkg._abi.RT_ERR_INVALID_ARGUMENT
