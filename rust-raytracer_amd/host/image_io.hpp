@@ -1,7 +1,6 @@
 // image_io.hpp -- host-side image helpers of the headless driver:
 //   * Radiance .hdr (RGBE) reader standing in for the `radiant` crate (src/io.rs:108);
 //   * PNG writer (8-bit RGB) standing in for io::save_colors_as_image (src/io.rs:310-336);
-//   * the bilateral filter of src/filter.rs:14-48 with its schedule from src/main.rs:114-132.
 // None of this is on the GPU path.
 #ifndef RT_HOST_IMAGE_IO_HPP
 #define RT_HOST_IMAGE_IO_HPP
@@ -173,41 +172,6 @@ inline void save_png(const std::string &path, const uint32_t *argb, uint32_t w, 
     detail::chunk(out, "IEND", {});
 }
 
-// bilateral_filter (src/filter.rs:14-48).  The neighbour index is computed in wrapping u32 arithmetic
-// exactly as the release build of the reference does: x - (half - i) wraps twice and comes out right
-// except where x - half + i is negative, which wraps to a huge value and clamps to the far edge.
-inline void bilateral_filter(const std::vector<float> &img, std::vector<float> &out, uint32_t w, uint32_t h,
-                             uint32_t diameter, float sigma_i, float sigma_s) {
-    const float kPi = 3.14159265358979323846f;
-    auto gaussian = [&](float x, float sigma) {
-        return std::exp(-(x * x) / (2.0f * sigma * sigma)) / (2.0f * kPi * sigma * sigma);
-    };
-    out.resize(img.size());
-    const uint32_t half = diameter / 2;
-    for (uint32_t cur = 0; cur < w * h; cur++) {
-        uint32_t x = cur % w, y = cur / w;
-        const float *p = &img[(size_t)cur * 3];
-        float current_sum = p[0] + p[1] + p[2];
-        float f[3] = {0, 0, 0}, weight_sum = 0.0f;
-        for (uint32_t i = 0; i < diameter; i++) {
-            for (uint32_t j = 0; j < diameter; j++) {
-                uint32_t xn = x - (half - i), yn = y - (half - j);  // wrapping
-                if (xn > w - 1) xn = w - 1;
-                if (yn > h - 1) yn = h - 1;
-                const float *q = &img[((size_t)yn * w + xn) * 3];
-                float neighbor_sum = q[0] + q[1] + q[2];
-                uint32_t dx = x - xn, dy = y - yn;
-                float dist = std::sqrt((float)(dx * dx + dy * dy));
-                float wgt = gaussian((1.0f / 3.0f) * (neighbor_sum - current_sum), sigma_i) * gaussian(dist, sigma_s);
-                f[0] += q[0] * wgt, f[1] += q[1] * wgt, f[2] += q[2] * wgt;
-                weight_sum += wgt;
-            }
-        }
-        out[(size_t)cur * 3] = f[0] / weight_sum;
-        out[(size_t)cur * 3 + 1] = f[1] / weight_sum;
-        out[(size_t)cur * 3 + 2] = f[2] / weight_sum;
-    }
-}
 
 }  // namespace imageio
 #endif
