@@ -95,7 +95,23 @@ def test_closest_hit_microbench_checks(pkg, oracle):
     assert st.rays == 3 * n  # two whole batches and one batch in two halves
 
 
-def test_rtrender_end_to_end(tmp_path, pkg):
+def _decode_png(path, W, H):
+    """Pixels of a PNG written with stored deflate blocks and filter 0, as 0xFFRRGGBB."""
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat = 8, b""
+    while pos < len(raw):
+        n = int.from_bytes(raw[pos:pos + 4], "big")
+        typ = raw[pos + 4:pos + 8]
+        if typ == b"IDAT":
+            idat += raw[pos + 8:pos + 8 + n]
+        assert zlib.crc32(raw[pos + 4:pos + 8 + n]) == int.from_bytes(raw[pos + 8 + n:pos + 12 + n], "big")
+        pos += 12 + n
+    px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, 1 + 3 * W)[:, 1:].reshape(H * W, 3).astype(np.uint32)
+    return (255 << 24) | (px[:, 0] << 16) | (px[:, 1] << 8) | px[:, 2]
+
+
+def test_rtrender_end_to_end(tmp_path, pkg, oracle):
     """The C++ host (reference command line) on a scene file written in the reference's schema gives the same
     frame as the Python mirror of Renderer::render with the same seed."""
     d = pkg.scenes.cornell()
@@ -112,20 +128,18 @@ def test_rtrender_end_to_end(tmp_path, pkg):
         buf = r.render(buf, pkg.Mode.Image)
     buf = buf / np.float32(passes)
     want = np.array([pkg.to_rgb(c, 1.0 / 2.2) for c in buf], dtype=np.uint32)
-    # decode the PNG (stored deflate blocks, filter 0)
-    raw = open(out, "rb").read()
-    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat = 8, b""
-    while pos < len(raw):
-        n = int.from_bytes(raw[pos:pos + 4], "big")
-        typ = raw[pos + 4:pos + 8]
-        if typ == b"IDAT":
-            idat += raw[pos + 8:pos + 8 + n]
-        assert zlib.crc32(raw[pos + 4:pos + 8 + n]) == int.from_bytes(raw[pos + 8 + n:pos + 12 + n], "big")
-        pos += 12 + n
-    px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, 1 + 3 * W)[:, 1:].reshape(H * W, 3).astype(np.uint32)
-    got = (255 << 24) | (px[:, 0] << 16) | (px[:, 1] << 8) | px[:, 2]
-    assert np.array_equal(got, want)
+    assert np.array_equal(_decode_png(out, W, H), want)
+    # -f: the three filter iterations of src/main.rs:114-132 before the display transform
+    out_f = tmp_path / "filtered.png"
+    subprocess.check_output([RTRENDER, str(scene_file), "--width", str(W), "--height", str(H), "-s", str(spp), "-p",
+                             str(passes), "-b", "8", "--seed", "5", "-f", "--out", str(out_f)])
+    cur = np.ascontiguousarray(buf, np.float32)
+    for i in (1, 2, 3):
+        nxt = np.empty_like(cur)
+        oracle.lib().oracle_bilateral_filter(cur.ctypes.data, nxt.ctypes.data, W, H, 9 // i, 0.05 / i, 1.0 / i)
+        cur = nxt
+    want_f = np.array([pkg.to_rgb(c, 1.0 / 2.2) for c in cur], dtype=np.uint32)
+    assert np.array_equal(_decode_png(out_f, W, H), want_f)
 
 
 @pytest.mark.gpu
