@@ -119,17 +119,6 @@ struct Item {
     Box box;
 };
 
-// Bvh::box_compare (src/tracer/bvh.rs:120-139); "centre" is max + min/2 as written there.
-inline int box_compare(const Box &a, const Box &b, int axis) {
-    float ca = a.hi[axis] + a.lo[axis] * 0.5f;
-    float cb = b.hi[axis] + b.lo[axis] * 0.5f;
-    if (a.lo[axis] < b.lo[axis] && a.hi[axis] > b.hi[axis]) return -1;
-    if (b.lo[axis] < a.lo[axis] && b.hi[axis] > a.hi[axis]) return 1;
-    if (ca < cb) return -1;
-    if (ca > cb) return 1;
-    return 0;
-}
-
 struct Builder {
     std::vector<BNode> nodes;
     std::atomic<int64_t> next_node{0};
@@ -146,28 +135,59 @@ struct Builder {
 
     // Stable top-down merge sort (split at n/2, ties keep the left run first).  The
     // comparator above is not a strict weak order, so the permutation depends on the
-    // algorithm; this one defines the tree.
-    void merge_sort(Item *a, Item *tmp, size_t n, int axis) {
-        if (n < 2) return;
+    // algorithm; this one defines the tree.  It runs on 16-byte keys (what the comparator reads of a
+    // box on one axis, and the item's position) that ping-pong between two buffers; the 28-byte
+    // items are moved once at the end.
+    // Bvh::box_compare (src/tracer/bvh.rs:120-139): a box that strictly contains the other on the axis sorts first,
+    // otherwise the "centres" decide, and the centre is max + min / 2 as written there.
+    struct Key {
+        float lo, hi, c;  // c = hi + lo / 2
+        uint32_t at;
+    };
+    static bool key_less(const Key &a, const Key &b) {  // box_compare(a, b, axis) == Less
+        if (a.lo < b.lo && a.hi > b.hi) return true;
+        if (b.lo < a.lo && b.hi > a.hi) return false;
+        return a.c < b.c;
+    }
+    // sorts a[0, n) with b as the other buffer; the result is left in a (to_a) or in b
+    void sort_keys(Key *a, Key *b, size_t n, bool to_a) {
+        if (n < 2) {
+            if (n == 1 && !to_a) b[0] = a[0];
+            return;
+        }
         size_t mid = n / 2;
         if (n > (1u << 15) && take_thread()) {
-            std::thread t([&]() { merge_sort(a, tmp, mid, axis); });
-            merge_sort(a + mid, tmp + mid, n - mid, axis);
+            std::thread t([&]() { sort_keys(a, b, mid, !to_a); });
+            sort_keys(a + mid, b + mid, n - mid, !to_a);
             t.join();
             give_thread();
         } else {
-            merge_sort(a, tmp, mid, axis);
-            merge_sort(a + mid, tmp + mid, n - mid, axis);
+            sort_keys(a, b, mid, !to_a);
+            sort_keys(a + mid, b + mid, n - mid, !to_a);
         }
+        const Key *src = to_a ? b : a;
+        Key *dst = to_a ? a : b;
         size_t i = 0, j = mid, k = 0;
         while (i < mid && j < n) {
-            if (box_compare(a[j].box, a[i].box, axis) < 0)
-                tmp[k++] = a[j++];
+            if (key_less(src[j], src[i]))
+                dst[k++] = src[j++];
             else
-                tmp[k++] = a[i++];
+                dst[k++] = src[i++];
         }
-        while (i < mid) tmp[k++] = a[i++];
-        while (j < n) tmp[k++] = a[j++];
+        while (i < mid) dst[k++] = src[i++];
+        while (j < n) dst[k++] = src[j++];
+    }
+    std::vector<Key> keys_a, keys_b;  // indexed like the item arrays (a run keeps its offsets)
+    const Item *items_base = nullptr;
+    void merge_sort(Item *a, Item *tmp, size_t n, int axis) {
+        if (n < 2) return;
+        Key *ka = keys_a.data() + (a - items_base), *kb = keys_b.data() + (a - items_base);
+        for (size_t i = 0; i < n; i++) {
+            const Box &b = a[i].box;
+            ka[i] = Key{b.lo[axis], b.hi[axis], b.hi[axis] + b.lo[axis] * 0.5f, (uint32_t)i};
+        }
+        sort_keys(ka, kb, n, true);
+        for (size_t i = 0; i < n; i++) tmp[i] = a[ka[i].at];
         std::memcpy(a, tmp, n * sizeof(Item));
     }
 
@@ -862,9 +882,12 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
         uint64_t biggest = 0;
         for (auto &s : mesh_spans) biggest = std::max(biggest, s.count);
         std::vector<Item> items(std::max<uint64_t>(biggest, world_items.size())), tmp(items.size());
+        B.keys_a.resize(items.size());
+        B.keys_b.resize(items.size());
         for (size_t mi = 0; mi < mesh_spans.size(); mi++) {
             const MeshSpan &s = mesh_spans[mi];
             for (uint64_t f = 0; f < s.count; f++) items[f] = Item{~(int32_t)(s.first + f), boxes[s.first + f]};
+            B.items_base = items.data();
             int32_t root = B.build(items.data(), tmp.data(), s.count, boxes, 0);
             if (root == kNone || B.too_deep) {
                 err = "mesh geometry too degenerate for the reference's median split";
@@ -873,6 +896,7 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
             world_items[mesh_world_slot[mi]] = Item{root, B.nodes[root].box};
         }
         std::vector<Item> wtmp(world_items.size());
+        B.items_base = world_items.data();
         int32_t root = B.build(world_items.data(), wtmp.data(), world_items.size(), boxes, 0);
         if (root == kNone || B.too_deep) {
             err = "scene too degenerate for the reference's median split";
