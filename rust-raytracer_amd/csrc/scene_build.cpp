@@ -177,11 +177,16 @@ struct Builder {
         while (i < mid) dst[k++] = src[i++];
         while (j < n) dst[k++] = src[j++];
     }
-    std::vector<Key> keys_a, keys_b;  // indexed like the item arrays (a run keeps its offsets)
-    const Item *items_base = nullptr;
-    void merge_sort(Item *a, Item *tmp, size_t n, int axis) {
+    // buffers that go with an item array, indexed like it (a run keeps its offsets)
+    struct Scratch {
+        Item *tmp;
+        Key *ka, *kb;
+        Scratch at(size_t off) const { return Scratch{tmp + off, ka + off, kb + off}; }
+    };
+    void merge_sort(Item *a, Scratch sc, size_t n, int axis) {
         if (n < 2) return;
-        Key *ka = keys_a.data() + (a - items_base), *kb = keys_b.data() + (a - items_base);
+        Item *tmp = sc.tmp;
+        Key *ka = sc.ka, *kb = sc.kb;
         for (size_t i = 0; i < n; i++) {
             const Box &b = a[i].box;
             ka[i] = Key{b.lo[axis], b.hi[axis], b.hi[axis] + b.lo[axis] * 0.5f, (uint32_t)i};
@@ -212,7 +217,7 @@ struct Builder {
     }
 
     // Bvh::new (src/tracer/bvh.rs:39-81)
-    int32_t build(Item *it, Item *tmp, size_t n, const std::vector<Box> &prim_boxes, int depth) {
+    int32_t build(Item *it, Scratch tmp, size_t n, const std::vector<Box> &prim_boxes, int depth) {
         if (depth > 4096) {
             too_deep = true;
             return kNone;
@@ -233,12 +238,12 @@ struct Builder {
             size_t mid = true_middle(it, n, axis);
             if (n > (1u << 14) && take_thread()) {
                 std::thread t([&]() { l = build(it, tmp, mid, prim_boxes, depth + 1); });
-                r = build(it + mid, tmp + mid, n - mid, prim_boxes, depth + 1);
+                r = build(it + mid, tmp.at(mid), n - mid, prim_boxes, depth + 1);
                 t.join();
                 give_thread();
             } else {
                 l = build(it, tmp, mid, prim_boxes, depth + 1);
-                r = build(it + mid, tmp + mid, n - mid, prim_boxes, depth + 1);
+                r = build(it + mid, tmp.at(mid), n - mid, prim_boxes, depth + 1);
             }
         }
         if (too_deep) return kNone;
@@ -881,23 +886,43 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
     {
         uint64_t biggest = 0;
         for (auto &s : mesh_spans) biggest = std::max(biggest, s.count);
-        std::vector<Item> items(std::max<uint64_t>(biggest, world_items.size())), tmp(items.size());
-        B.keys_a.resize(items.size());
-        B.keys_b.resize(items.size());
-        for (size_t mi = 0; mi < mesh_spans.size(); mi++) {
-            const MeshSpan &s = mesh_spans[mi];
-            for (uint64_t f = 0; f < s.count; f++) items[f] = Item{~(int32_t)(s.first + f), boxes[s.first + f]};
-            B.items_base = items.data();
-            int32_t root = B.build(items.data(), tmp.data(), s.count, boxes, 0);
-            if (root == kNone || B.too_deep) {
-                err = "mesh geometry too degenerate for the reference's median split";
-                return RT_ERR_INTERNAL;
+        // one tree per mesh (src/tracer/mesh.rs:75-83); the meshes are independent, so they are built side by side
+        // (a mesh large enough to use the threads itself takes them from the same pool)
+        std::atomic<size_t> next_mesh{0};
+        std::atomic<bool> failed{false};
+        auto mesh_worker = [&]() {
+            std::vector<Item> items(biggest), tmp(biggest);
+            std::vector<Builder::Key> ka(biggest), kb(biggest);
+            for (;;) {
+                size_t mi = next_mesh.fetch_add(1);
+                if (mi >= mesh_spans.size() || failed) break;
+                const MeshSpan &s = mesh_spans[mi];
+                for (uint64_t f = 0; f < s.count; f++) items[f] = Item{~(int32_t)(s.first + f), boxes[s.first + f]};
+                int32_t root = B.build(items.data(), Builder::Scratch{tmp.data(), ka.data(), kb.data()}, s.count, boxes, 0);
+                if (root == kNone || B.too_deep) {
+                    failed = true;
+                    break;
+                }
+                world_items[mesh_world_slot[mi]] = Item{root, B.nodes[root].box};
             }
-            world_items[mesh_world_slot[mi]] = Item{root, B.nodes[root].box};
+        };
+        {
+            // small meshes: one worker per thread; large ones: few workers, the rest of the pool serves the sorts
+            size_t workers = biggest > (1u << 20) ? 1 : std::min<size_t>(hw, mesh_spans.size());
+            std::vector<std::thread> pool;
+            if (workers > 1) B.spare_threads = (int)hw - (int)workers;
+            for (size_t w = 1; w < workers; w++) pool.emplace_back(mesh_worker);
+            if (!mesh_spans.empty()) mesh_worker();
+            for (auto &t : pool) t.join();
+            B.spare_threads = (int)hw - 1;
+        }
+        if (failed) {
+            err = "mesh geometry too degenerate for the reference's median split";
+            return RT_ERR_INTERNAL;
         }
         std::vector<Item> wtmp(world_items.size());
-        B.items_base = world_items.data();
-        int32_t root = B.build(world_items.data(), wtmp.data(), world_items.size(), boxes, 0);
+        std::vector<Builder::Key> wka(world_items.size()), wkb(world_items.size());
+        int32_t root = B.build(world_items.data(), Builder::Scratch{wtmp.data(), wka.data(), wkb.data()}, world_items.size(), boxes, 0);
         if (root == kNone || B.too_deep) {
             err = "scene too degenerate for the reference's median split";
             return RT_ERR_INTERNAL;
