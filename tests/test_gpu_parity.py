@@ -260,3 +260,33 @@ def test_deep_stacks_spill_to_the_overflow_area(pkg, oracle):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     rays = np.concatenate([o, d], axis=1).astype(np.float32)
     check_hits(pkg, oracle, S, rays, 0.00015, 100000.0)
+
+
+def test_visit_order_decides_between_coincident_triangles(pkg, oracle):
+    """A 200 x 200 height field in which every face exists twice (80,000 coincident pairs, one mesh, large enough for
+    the threaded sort): every hit is a tie between twins, and which twin wins depends on the reference's visit order,
+    i.e. on the exact permutation its stable sort with the odd comparator produces at every level of the build."""
+    n = 201
+    rng = np.random.default_rng(8)
+    gx, gz = np.meshgrid(np.linspace(-2, 2, n), np.linspace(-2, 2, n), indexing="ij")
+    gy = 0.2 * np.sin(3 * gx) * np.cos(2 * gz) + 0.01 * rng.random((n, n))
+    pos = np.stack([gx, gy, gz], axis=-1).reshape(-1, 3).astype(np.float32)
+    nrm = np.tile(np.float32([0, 1, 0]), (n * n, 1))
+    i, j = np.meshgrid(np.arange(n - 1), np.arange(n - 1), indexing="ij")
+    a = (i * n + j).ravel()
+    faces = np.concatenate([np.stack([a, a + 1, a + n], 1), np.stack([a + 1, a + n + 1, a + n], 1)])
+    twice = np.concatenate([faces, faces])  # every face twice, in a shuffled order: either twin may be declared first
+    order = rng.permutation(len(twice))
+    faces_of = twice[order].astype(np.uint32)
+    first_copy = order < len(faces)
+    S = pkg.SceneDescription()
+    m = S.add_material(pkg.lambertian((0.5, 0.5, 0.5)))
+    S.add_mesh(pos, nrm, faces_of, m)
+    m_rays = 200_000
+    o = np.stack([rng.uniform(-2, 2, m_rays), np.full(m_rays, 3.0), rng.uniform(-2, 2, m_rays)], 1)
+    d = np.stack([rng.normal(0, 0.2, m_rays), -np.ones(m_rays), rng.normal(0, 0.2, m_rays)], 1)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    ids = check_hits(pkg, oracle, S, np.concatenate([o, d], 1).astype(np.float32))
+    hit = ids >= 0
+    assert hit.mean() > 0.5
+    assert first_copy[ids[hit]].any() and (~first_copy[ids[hit]]).any()  # either copy wins somewhere
