@@ -960,7 +960,7 @@ static int closest_hit_device(RtScene *s, const float *d_org_dir, float t_min, f
     if (!s || (n && !d_org_dir)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return RT_OK;
     RT_HIP(hipSetDevice(s->device));
-    const size_t chunk_max = 1u << 24;
+    const size_t chunk_max = 1u << 27;  // rays per launch: large launches keep the tail of the persistent kernel small
     int rc = ensure_work(s, std::min(n, chunk_max));
     if (rc) return rc;
     for (size_t off = 0; off < n; off += chunk_max) {
