@@ -1,0 +1,12 @@
+#!/bin/bash
+# Host-only check: the scene builder (csrc/scene_build.cpp: threaded sorts, per-mesh builds, cost-table collapse,
+# rebuilt interior) under the address and undefined-behaviour sanitizers of g++.  No GPU code is involved.
+# Usage: bash tools/host_sanitize/run.sh     (from the repository root; takes a few minutes)
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+OUT=${TMPDIR:-/tmp}/rtcore_host_sanitize
+mkdir -p "$OUT"
+g++ -std=c++17 -O1 -g -fsanitize=address,undefined -static-libasan -static-libubsan -fno-omit-frame-pointer \
+    -ffp-contract=off -mavx2 -mfma -I"$ROOT/rust-raytracer_amd/csrc" -I"$ROOT/include" \
+    "$ROOT/tools/host_sanitize/build_harness.cpp" "$ROOT/rust-raytracer_amd/csrc/scene_build.cpp" -o "$OUT/harness" -lpthread
+ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 "$OUT/harness"
