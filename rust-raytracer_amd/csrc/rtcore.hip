@@ -670,6 +670,19 @@ int check_params(const RtScene *s, const RtRenderParams *p, const void *buf) {
     return RT_OK;
 }
 
+// Paths (or rays) in flight per launch when the caller leaves the choice to the core: up to 128 M
+// (128 B of work state each), at most a quarter of the free HBM, at least 1 M.
+uint64_t default_paths_in_flight(const RtScene *s) {
+    uint64_t budget = 1ull << 27;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        uint64_t fit = (uint64_t)(free_b + s->work_paths * 128ull) / 4ull / 128ull;
+        if (fit < (1ull << 20)) fit = 1ull << 20;
+        if (budget > fit) budget = fit;
+    }
+    return budget;
+}
+
 // One pass (or one preview frame) on device memory.
 int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream_t stream, bool preview) {
     int rc = check_params(s, p, d_accum);
@@ -682,15 +695,7 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
     // (10 M-triangle scene at 4K: 1.35 / 1.70 / 1.96 / 2.12 Grays/s at 4 / 8 / 16 / 32 M paths).
     // Default: the whole pass, up to 128 M paths (128 B of state each) or a quarter of the free HBM.
     uint64_t budget = p->batch_paths;
-    if (budget == 0) {
-        budget = 1ull << 27;
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            uint64_t fit = (uint64_t)(free_b + s->work_paths * 128ull) / 4ull / 128ull;
-            if (fit < (1ull << 20)) fit = 1ull << 20;
-            if (budget > fit) budget = fit;
-        }
-    }
+    if (budget == 0) budget = default_paths_in_flight(s);
     if (budget > (1ull << 30)) budget = 1ull << 30;
     uint64_t np_max = budget / spp;
     if (np_max == 0) np_max = 1;
@@ -960,7 +965,7 @@ static int closest_hit_device(RtScene *s, const float *d_org_dir, float t_min, f
     if (!s || (n && !d_org_dir)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     if (n == 0) return RT_OK;
     RT_HIP(hipSetDevice(s->device));
-    const size_t chunk_max = 1u << 27;  // rays per launch: large launches keep the tail of the persistent kernel small
+    const size_t chunk_max = (size_t)default_paths_in_flight(s);  // large launches keep the tail of the persistent kernel small
     int rc = ensure_work(s, std::min(n, chunk_max));
     if (rc) return rc;
     for (size_t off = 0; off < n; off += chunk_max) {
