@@ -163,6 +163,11 @@ typedef struct RtRenderParams {
     uint32_t pass_index;  /* global index of this pass (0-based) */
     uint32_t seed;
     uint64_t batch_paths; /* paths in flight per wavefront batch; 0 = default */
+    /* Render only pixels [first_pixel, first_pixel + pixel_count) of the frame (row-major from the top row, the
+     * index p of src/render.rs:163-176); pixel_count 0 = the whole frame.  The buffer is the whole frame either
+     * way.  Pixels are independent within a pass, so ranges split one pass over several GPUs. */
+    uint64_t first_pixel;
+    uint64_t pixel_count;
 } RtRenderParams;
 
 typedef struct RtSceneInfo {

@@ -1007,6 +1007,7 @@ int oracle_render_range(OracleScene *s, const RtRenderParams *p, uint64_t first_
                         int threads);
 int oracle_render_pass(OracleScene *s, const RtRenderParams *p, float *accum, int threads) {
     if (!p) return RT_ERR_INVALID_ARGUMENT;
+    if (p->pixel_count) return oracle_render_range(s, p, p->first_pixel, p->pixel_count, accum, threads);
     return oracle_render_range(s, p, 0, (uint64_t)p->width * p->height, accum, threads);
 }
 // The same for pixels [first_pixel, first_pixel + n_pixels) of the frame only; `accum` still addresses the

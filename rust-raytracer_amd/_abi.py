@@ -99,6 +99,8 @@ class RtRenderParams(C.Structure):
         ("pass_index", C.c_uint32),
         ("seed", C.c_uint32),
         ("batch_paths", C.c_uint64),
+        ("first_pixel", C.c_uint64),
+        ("pixel_count", C.c_uint64),
     ]
 
 

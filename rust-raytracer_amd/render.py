@@ -89,8 +89,11 @@ class Scene:
     # ---- passes ------------------------------------------------------------
     @staticmethod
     def params(width, height, samples, max_bounce, light_clamp=math.inf, mode=Mode.Image, pass_index=0, seed=0,
-               batch_paths=0):
+               batch_paths=0, first_pixel=0, pixel_count=0):
+        """pixel_count > 0 renders only pixels [first_pixel, first_pixel + pixel_count) of the frame (row-major from
+        the top row); the buffer is the whole frame either way."""
         p = _abi.RtRenderParams()
+        p.first_pixel, p.pixel_count = first_pixel, pixel_count
         p.width, p.height, p.samples, p.max_bounce = width, height, samples, max_bounce
         p.light_clamp = light_clamp
         p.mode, p.pass_index, p.seed, p.batch_paths = mode, pass_index, seed, batch_paths

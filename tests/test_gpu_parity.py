@@ -290,3 +290,24 @@ def test_visit_order_decides_between_coincident_triangles(pkg, oracle):
     hit = ids >= 0
     assert hit.mean() > 0.5
     assert first_copy[ids[hit]].any() and (~first_copy[ids[hit]]).any()  # either copy wins somewhere
+
+
+def test_pixel_ranges_of_a_pass(pkg, oracle):
+    """RtRenderParams.first_pixel / pixel_count: the ranges of a pass rendered one by one (here in three uneven
+    pieces, one of them through several batches) give the frame of the whole pass, and leave the rest untouched."""
+    d = pkg.scenes.rtiow(seed=4)
+    scene, ora = pkg.Scene(d), oracle.OracleScene(d)
+    W, H, spp = 80, 50, 5
+    whole = np.zeros(W * H * 3, np.float32)
+    ora.render_pass(whole, pkg.Scene.params(W, H, spp, 8, pass_index=2, seed=9))
+    acc = np.zeros(W * H * 3, np.float32)
+    for first, count, batch in ((0, 1234, 0), (1234, 1, 0), (1235, W * H - 1235, 700)):
+        before = acc.copy()
+        scene.render_pass(acc, pkg.Scene.params(W, H, spp, 8, pass_index=2, seed=9, first_pixel=first, pixel_count=count,
+                                                batch_paths=batch))
+        outside = np.ones(W * H * 3, bool)
+        outside[3 * first:3 * (first + count)] = False
+        assert np.array_equal(acc[outside].view(np.uint32), before[outside].view(np.uint32))
+    assert np.array_equal(acc.view(np.uint32), whole.view(np.uint32))
+    with pytest.raises(pkg.RtError):
+        scene.render_pass(acc, pkg.Scene.params(W, H, spp, 8, first_pixel=W * H - 3, pixel_count=4))

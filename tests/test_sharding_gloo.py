@@ -73,3 +73,50 @@ def test_pass_partition(pkg):
     for world in (1, 2, 3, 8):
         seen = sorted(sum((pkg.parallel.passes_for_rank(r, world, 21) for r in range(world)), []))
         assert seen == list(range(21))
+
+
+def _frame_worker(rank, world, port, out_path):
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as ge
+    import oracle_binding as ob
+
+    pkg = ge.load_package()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    ora = ob.OracleScene(pkg.scenes.cornell())
+    accum = torch.zeros(W * H * 3, dtype=torch.float32)
+
+    def render_range(buf, first, count):
+        p = pkg.Scene.params(W, H, SPP, BOUNCES, pass_index=3, seed=SEED, first_pixel=first, pixel_count=count)
+        ora.render_pass(buf.numpy(), p, threads=2)
+
+    first, count = pkg.parallel.render_split_frame(render_range, accum, W * H, rank, world, dist=dist)
+    assert (first, count) == pkg.parallel.pixels_for_rank(rank, world, W * H)
+    if rank == 0:
+        np.save(out_path, accum.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_pass_split_by_pixel_ranges_equals_single_process(tmp_path, pkg, oracle):
+    """The single-pass alternative: the frame is cut into pixel ranges, one per rank; the reduce of the zero-padded
+    pieces is bit for bit the frame one process renders."""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "split.npy")
+    mp.spawn(_frame_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    whole = np.zeros(W * H * 3, np.float32)
+    oracle.OracleScene(pkg.scenes.cornell()).render_pass(whole, pkg.Scene.params(W, H, SPP, BOUNCES, pass_index=3, seed=SEED),
+                                                         threads=2)
+    assert np.array_equal(np.load(out).view(np.uint32), whole.view(np.uint32))
+
+
+def test_pixel_partition(pkg):
+    for world in (1, 2, 3, 8):
+        for n in (1, 7, 48 * 32, 3840 * 2160):
+            spans = [pkg.parallel.pixels_for_rank(r, world, n) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))
