@@ -21,14 +21,29 @@
  *   - one host thread drives one scene at a time; a scene lives on the HIP
  *     device that was current when it was created;
  *   - "_device" variants take device pointers and a hipStream_t (as void*) and
- *     never synchronise with the host; the others take host pointers, copy and
- *     synchronise.
+ *     only enqueue work: no host synchronisation, except that the first call on
+ *     a scene (and any later call that needs larger work buffers than every call
+ *     before it) allocates those buffers and asks the device once for its free
+ *     memory; the others take host pointers, copy and synchronise.
  *
  * prim_id: the reference's HitRecord carries no primitive identity
  * (src/tracer/hittable.rs:13-19).  Here a primitive id is the index in scene
  * declaration order: object i of RtSceneDesc::objects contributes one id, except
  * a mesh object, which contributes one id per face, in face order.  Ids are
  * assigned in object order with no gaps; -1 means "no hit".
+ *
+ * Equal distances: when two primitives are hit at exactly the same t, the
+ * reference's winner follows from the order in which Bvh::hit reaches them
+ * (right child first, src/tracer/bvh.rs:148-157) and from each primitive's own
+ * bound check (a triangle and a box entry face accept t == t_max, a sphere and a
+ * box exit face do not).  The core returns the winner of that rule for the tree
+ * ITS build produces.  Bvh::new sorts with a comparator that is not a strict weak
+ * order (src/tracer/bvh.rs:120-139), so the tree, and with it the winner among
+ * exactly coincident hits, depends on the sort algorithm: the core uses a plain
+ * stable top-down merge sort, Rust's slice::sort_by is a different stable merge
+ * sort (run-detecting; driftsort from 1.81), and the two are not proven to give
+ * the same permutation.  t is the same either way; only which of several
+ * primitives at one identical t is named can differ.
  */
 #ifndef RTCORE_H
 #define RTCORE_H
@@ -245,6 +260,22 @@ int rt_closest_hit_batch_device(RtScene *scene, const float *d_org_dir, float t_
 int rt_closest_hit_batch_counted_device(RtScene *scene, const float *d_org_dir, float t_min,
                                         float t_max, size_t n, int32_t *d_prim_id, float *d_t,
                                         float *d_normal, float *d_point, void *stream);
+
+/*
+ * rt_closest_hit_batch_device for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same kernels and
+ * same results as rt_closest_hit_batch_device; the work memory (packed rays, hit records, the launch's work
+ * counter, the overflow area of the traversal stacks) is a 64 MiB array that each GPU the library runs on
+ * holds from load time until the process ends, so the call issues no hipMalloc / hipFree and creates no events.
+ * Limits: n <= RT_NOALLOC_MAX_RAYS per call (RT_ERR_INVALID_ARGUMENT beyond it); the launch uses fewer blocks
+ * when the scene's tree is deep, so that the stacks' overflow area fits.  RtStats is not updated.  Every call
+ * on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) race; calls on
+ * one stream are ordered and safe.
+ */
+#define RT_NOALLOC_MAX_RAYS 262144u
+int rt_closest_hit_batch_noalloc_device(RtScene *scene, const float *d_org_dir, float t_min, float t_max,
+                                        size_t n, int32_t *d_prim_id, float *d_t, float *d_normal,
+                                        float *d_point, void *stream);
 
 /* When nonzero, render passes time their stages with HIP events into RtStats (adds syncs). */
 int rt_set_stage_timing(RtScene *scene, int enabled);

@@ -22,6 +22,7 @@ RT_ERR_INTERNAL = -5
 RT_MAT_DIELECTRIC, RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_GLOSSY = 0, 1, 2, 3
 RT_OBJ_SPHERE, RT_OBJ_ABOX, RT_OBJ_CUBE, RT_OBJ_TRIANGLE, RT_OBJ_MESH = 0, 1, 2, 3, 4
 RT_MODE_NORMALS, RT_MODE_COLORS, RT_MODE_IMAGE = 0, 1, 2
+RT_NOALLOC_MAX_RAYS = 262144
 
 F3 = C.c_float * 3
 F9 = C.c_float * 9
@@ -153,6 +154,10 @@ SYMBOLS = {
     "rt_closest_hit_batch": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_size_t, _VP, _VP, _VP, _VP]),
     "rt_closest_hit_batch_device": (C.c_int, [_VP, _VP, C.c_float, C.c_float, C.c_size_t, _VP, _VP, _VP, _VP, _VP]),
     "rt_closest_hit_batch_counted_device": (
+        C.c_int,
+        [_VP, _VP, C.c_float, C.c_float, C.c_size_t, _VP, _VP, _VP, _VP, _VP],
+    ),
+    "rt_closest_hit_batch_noalloc_device": (
         C.c_int,
         [_VP, _VP, C.c_float, C.c_float, C.c_size_t, _VP, _VP, _VP, _VP, _VP],
     ),

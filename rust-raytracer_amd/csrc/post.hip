@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <mutex>
 #include <string>
 
 #include "../../include/rtcore.h"
@@ -114,22 +115,54 @@ int rt_bilateral_filter_device(const float *d_in, float *d_out, uint32_t width, 
 }
 
 // Host-buffer variants: copy in, run the kernels above on the current device, copy out, synchronise.
+// The staging buffers are kept per device and only ever grow, so a host that tonemaps every pass
+// (src/main.rs:266-271) pays for the allocations once; one call at a time (the mutex is held across the call).
+namespace {
+struct Staging {
+    void *in = nullptr, *out = nullptr;
+    size_t in_bytes = 0, out_bytes = 0;
+};
+std::mutex g_staging_mutex;
+Staging g_staging[64];
+
+int grow(void **p, size_t *have, size_t want) {
+    if (want <= *have) return RT_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return rt_set_error_message(e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE, hipGetErrorString(e));
+    }
+    *have = want;
+    return RT_OK;
+}
+int staging_for(size_t in_bytes, size_t out_bytes, Staging **st) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return rt_set_error_message(RT_ERR_DEVICE, hipGetErrorString(e));
+    if (dev < 0 || dev >= 64) return rt_set_error_message(RT_ERR_DEVICE, "device index out of range");
+    Staging *s = &g_staging[dev];
+    int rc = grow(&s->in, &s->in_bytes, in_bytes);
+    if (rc == RT_OK) rc = grow(&s->out, &s->out_bytes, out_bytes);
+    *st = s;
+    return rc;
+}
+}  // namespace
+
 int rt_tonemap(const float *rgb, size_t n_pixels, float divisor, float inv_gamma, uint32_t *argb) {
     if (!rgb || !argb) return rt_set_error_message(RT_ERR_INVALID_ARGUMENT, "null argument");
     if (n_pixels == 0) return RT_OK;
-    float *d_in = nullptr;
-    uint32_t *d_out = nullptr;
-    int rc = RT_OK;
-    hipError_t e = hipMalloc((void **)&d_in, n_pixels * 12);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, n_pixels * 4);
-    if (e != hipSuccess) rc = rt_set_error_message(e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE, hipGetErrorString(e));
-    if (rc == RT_OK && (e = hipMemcpy(d_in, rgb, n_pixels * 12, hipMemcpyHostToDevice)) != hipSuccess)
+    std::lock_guard<std::mutex> lock(g_staging_mutex);
+    Staging *st = nullptr;
+    int rc = staging_for(n_pixels * 12, n_pixels * 4, &st);
+    hipError_t e;
+    if (rc == RT_OK && (e = hipMemcpy(st->in, rgb, n_pixels * 12, hipMemcpyHostToDevice)) != hipSuccess)
         rc = rt_set_error_message(RT_ERR_DEVICE, hipGetErrorString(e));
-    if (rc == RT_OK) rc = rt_tonemap_device(d_in, n_pixels, divisor, inv_gamma, d_out, nullptr);
-    if (rc == RT_OK && (e = hipMemcpy(argb, d_out, n_pixels * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+    if (rc == RT_OK) rc = rt_tonemap_device((const float *)st->in, n_pixels, divisor, inv_gamma, (uint32_t *)st->out, nullptr);
+    if (rc == RT_OK && (e = hipMemcpy(argb, st->out, n_pixels * 4, hipMemcpyDeviceToHost)) != hipSuccess)
         rc = rt_set_error_message(RT_ERR_DEVICE, hipGetErrorString(e));
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
     return rc;
 }
 
@@ -139,18 +172,16 @@ int rt_bilateral_filter(const float *in, float *out, uint32_t width, uint32_t he
     if (width == 0 || height == 0 || (uint64_t)width * height > 0x7fffffffull)
         return rt_set_error_message(RT_ERR_INVALID_ARGUMENT, "bad frame size");
     const size_t bytes = (size_t)width * height * 12;
-    float *d_in = nullptr, *d_out = nullptr;
-    int rc = RT_OK;
-    hipError_t e = hipMalloc((void **)&d_in, bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_out, bytes);
-    if (e != hipSuccess) rc = rt_set_error_message(e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE, hipGetErrorString(e));
-    if (rc == RT_OK && (e = hipMemcpy(d_in, in, bytes, hipMemcpyHostToDevice)) != hipSuccess)
+    std::lock_guard<std::mutex> lock(g_staging_mutex);
+    Staging *st = nullptr;
+    int rc = staging_for(bytes, bytes, &st);
+    hipError_t e;
+    if (rc == RT_OK && (e = hipMemcpy(st->in, in, bytes, hipMemcpyHostToDevice)) != hipSuccess)
         rc = rt_set_error_message(RT_ERR_DEVICE, hipGetErrorString(e));
-    if (rc == RT_OK) rc = rt_bilateral_filter_device(d_in, d_out, width, height, diameter, sigma_i, sigma_s, nullptr);
-    if (rc == RT_OK && (e = hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost)) != hipSuccess)
+    if (rc == RT_OK)
+        rc = rt_bilateral_filter_device((const float *)st->in, (float *)st->out, width, height, diameter, sigma_i, sigma_s, nullptr);
+    if (rc == RT_OK && (e = hipMemcpy(out, st->out, bytes, hipMemcpyDeviceToHost)) != hipSuccess)
         rc = rt_set_error_message(RT_ERR_DEVICE, hipGetErrorString(e));
-    (void)hipFree(d_in);
-    (void)hipFree(d_out);
     return rc;
 }
 

@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -529,6 +530,10 @@ int fail(int code, const std::string &msg) {
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }  // a scene that fails half-way through its uploads frees what it already holds
     int ensure(size_t want) {
         if (want <= bytes) return RT_OK;
         if (p) (void)hipFree(p);
@@ -559,12 +564,13 @@ struct RtScene {
     int device = 0;
     int n_cus = 256;
     rtcore::HostScene host;  // metadata only after upload (big arrays are released)
-    DevBuf nodes, prims, normals, materials, env;
+    DevBuf nodes, prims, shade_records, materials, env;
     RtSceneView view{};
     // work buffers
-    DevBuf st_o[2], st_d[2], st_thr[2], hit_a, hit_n, rad, counts, totals, ovf, counters, accum_tmp, io_a, io_b, io_c,
+    DevBuf st_o[2], st_d[2], st_thr[2], hit_a, rad, counts, totals, ovf, counters, accum_tmp, io_a, io_b, io_c,
         io_d, io_e;
     uint64_t work_paths = 0;
+    uint64_t paths_in_flight = 0;  // default batch size, fixed at the first call that needs it
     uint32_t extend_blocks = 0;
     bool timing = false;
     bool counting = false;
@@ -576,6 +582,14 @@ struct RtScene {
 };
 
 namespace {
+
+// persistent waves: a launch is as many blocks as are resident at once
+uint32_t resident_extend_blocks(int n_cus) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, extend_kernel<false>, kBlock, 0) != hipSuccess || per_cu < 1)
+        per_cu = 4;
+    return (uint32_t)n_cus * (uint32_t)per_cu;
+}
 
 int ensure_work(RtScene *s, uint64_t paths) {
     if (paths <= s->work_paths && s->extend_blocks) return RT_OK;
@@ -596,12 +610,7 @@ int ensure_work(RtScene *s, uint64_t paths) {
         if ((rc = s->counters.ensure(128))) return rc;
         RT_HIP(hipMemset(s->counters.p, 0, 128));
     }
-    {   // persistent waves: launch what is resident at once
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, extend_kernel<false>, kBlock, 0) != hipSuccess || per_cu < 1)
-            per_cu = 4;
-        s->extend_blocks = (uint32_t)s->n_cus * (uint32_t)per_cu;
-    }
+    if (!s->extend_blocks) s->extend_blocks = resident_extend_blocks(s->n_cus);
     uint32_t deep = s->view.max_stack > RT_LDS_STACK ? s->view.max_stack - RT_LDS_STACK : 0;
     if (deep) {
         if ((rc = s->ovf.ensure((size_t)deep * s->extend_blocks * kBlock * sizeof(uint2)))) return rc;
@@ -660,6 +669,37 @@ int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4
     return RT_OK;
 }
 
+// ---- work memory of the entry point that allocates nothing (rt_closest_hit_batch_noalloc_device) ----
+// One array per GPU, held from the moment the library's code is loaded on that GPU until the process ends.
+// Layout: [0, 256) the launch's work counter; packed ray origins, packed directions, hits for kNoAllocMaxRays
+// rays; the rest is the overflow area of the traversal stacks.  In host code the array's NAME is not a device
+// address: the address on each device comes from hipGetSymbolAddress (scratch_base) and only that goes to kernels.
+constexpr size_t kNoAllocMaxRays = 1u << 18;
+constexpr size_t kScratchBytes = 64ull << 20;
+constexpr size_t kScratchRo = 256, kScratchRd = kScratchRo + kNoAllocMaxRays * 16, kScratchHit = kScratchRd + kNoAllocMaxRays * 16,
+                 kScratchOvf = kScratchHit + kNoAllocMaxRays * 8;
+static_assert(kScratchOvf % 256 == 0 && kScratchOvf < kScratchBytes, "scratch layout");
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+void *g_scratch_base[kMaxDevices];  // per device: each GPU holds its own copy of the array at its own address
+std::mutex g_scratch_mutex;
+
+// The array's address on `device`, which must be the current device.  Resolved once per device.
+int scratch_base(int device, unsigned char **out) {
+    if (device < 0 || device >= kMaxDevices) return fail(RT_ERR_DEVICE, "device index out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_base[device]) {
+        void *ptr = nullptr;
+        hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr)
+            return fail(RT_ERR_DEVICE, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_scratch_base[device] = ptr;
+    }
+    *out = (unsigned char *)g_scratch_base[device];
+    return RT_OK;
+}
+
 int check_params(const RtScene *s, const RtRenderParams *p, const void *buf) {
     if (!s || !p || !buf) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     if (p->width < 2 || p->height < 2) return fail(RT_ERR_INVALID_ARGUMENT, "width and height must be at least 2");
@@ -674,8 +714,10 @@ int check_params(const RtScene *s, const RtRenderParams *p, const void *buf) {
 }
 
 // Paths (or rays) in flight per launch when the caller leaves the choice to the core: up to 128 M
-// (128 B of work state each), at most a quarter of the free HBM, at least 1 M.
-uint64_t default_paths_in_flight(const RtScene *s) {
+// (128 B of work state each), at most a quarter of the free HBM, at least 1 M.  Asked of the device
+// once per scene (hipMemGetInfo synchronises with the host), then kept.
+uint64_t default_paths_in_flight(RtScene *s) {
+    if (s->paths_in_flight) return s->paths_in_flight;
     uint64_t budget = 1ull << 27;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -683,6 +725,7 @@ uint64_t default_paths_in_flight(const RtScene *s) {
         if (fit < (1ull << 20)) fit = 1ull << 20;
         if (budget > fit) budget = fit;
     }
+    s->paths_in_flight = budget;
     return budget;
 }
 
@@ -796,7 +839,10 @@ int rt_init(int device) {
         if (device >= n) return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
         RT_HIP(hipSetDevice(device));
     }
-    return RT_OK;
+    int cur = 0;
+    RT_HIP(hipGetDevice(&cur));
+    unsigned char *base = nullptr;
+    return scratch_base(cur, &base);  // the no-allocation entry point's work memory on this device
 }
 
 int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
@@ -813,6 +859,7 @@ int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
     hipDeviceProp_t prop;
     RT_HIP(hipGetDeviceProperties(&prop, s->device));
     s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    s->extend_blocks = resident_extend_blocks(s->n_cus);
 
     rtcore::HostScene &h = s->host;
     auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
@@ -825,13 +872,13 @@ int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
     };
     if ((rc = upload(s->nodes, h.nodes.data(), h.nodes.size() * 4))) return rc;
     if ((rc = upload(s->prims, h.prims.data(), h.prims.size() * 4))) return rc;
-    if ((rc = upload(s->normals, h.shade_records.data(), h.shade_records.size() * 4))) return rc;
+    if ((rc = upload(s->shade_records, h.shade_records.data(), h.shade_records.size() * 4))) return rc;
     if ((rc = upload(s->materials, h.materials.data(), h.materials.size() * sizeof(RtDevMaterial)))) return rc;
     if ((rc = upload(s->env, h.env.data(), h.env.size() * 4))) return rc;
     RtSceneView &v = s->view;
     v.nodes = s->nodes.p;
     v.prims = s->prims.p;
-    v.shade_records = s->normals.p;
+    v.shade_records = s->shade_records.p;
     v.materials = s->materials.p;
     v.env = (const float *)s->env.p;
     v.env_w = h.env_w;
@@ -873,12 +920,8 @@ int rt_scene_destroy(RtScene *s) {
     if (!s) return RT_OK;
     (void)hipSetDevice(s->device);
     (void)hipDeviceSynchronize();
-    DevBuf *all[] = {&s->nodes, &s->prims, &s->normals, &s->materials, &s->env, &s->st_o[0], &s->st_o[1], &s->st_d[0],
-                     &s->st_d[1], &s->st_thr[0], &s->st_thr[1], &s->hit_a, &s->hit_n, &s->rad, &s->counts, &s->totals,
-                     &s->ovf, &s->counters, &s->accum_tmp, &s->io_a, &s->io_b, &s->io_c, &s->io_d, &s->io_e};
-    for (DevBuf *b : all) b->release();
     for (hipEvent_t e : s->event_pool) (void)hipEventDestroy(e);
-    delete s;
+    delete s;  // the buffers free themselves
     return RT_OK;
 }
 
@@ -956,7 +999,9 @@ static int render_host(RtScene *s, const RtRenderParams *p, float *buf, bool pre
     RT_HIP(hipSetDevice(s->device));
     size_t bytes = (size_t)p->width * p->height * 3 * sizeof(float);
     if ((rc = s->accum_tmp.ensure(bytes))) return rc;
-    if (!preview) RT_HIP(hipMemcpy(s->accum_tmp.p, buf, bytes, hipMemcpyHostToDevice));
+    // a pass adds to the caller's frame; a preview overwrites it, but only inside the pixel range it renders:
+    // the rest of the caller's buffer must come back as it went in
+    if (!preview || p->pixel_count != 0) RT_HIP(hipMemcpy(s->accum_tmp.p, buf, bytes, hipMemcpyHostToDevice));
     if ((rc = render_device(s, p, (float *)s->accum_tmp.p, nullptr, preview))) return rc;
     RT_HIP(hipMemcpy(buf, s->accum_tmp.p, bytes, hipMemcpyDeviceToHost));
     return RT_OK;
@@ -1002,6 +1047,47 @@ int rt_closest_hit_batch_device(RtScene *s, const float *d_org_dir, float t_min,
 int rt_closest_hit_batch_counted_device(RtScene *s, const float *d_org_dir, float t_min, float t_max, size_t n,
                                         int32_t *d_id, float *d_t, float *d_normal, float *d_point, void *stream) {
     return closest_hit_device(s, d_org_dir, t_min, t_max, n, d_id, d_t, d_normal, d_point, (hipStream_t)stream, true);
+}
+
+// The closest-hit batch for callers that cannot allocate: same kernels as closest_hit_device, work memory in the
+// per-device `scratch` array.  Calls no hipMalloc / hipFree; no events, no counters on the scene.
+int rt_closest_hit_batch_noalloc_device(RtScene *s, const float *d_org_dir, float t_min, float t_max, size_t n,
+                                        int32_t *d_id, float *d_t, float *d_normal, float *d_point, void *stream_) {
+    if (!s || (n && !d_org_dir)) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    if (n > kNoAllocMaxRays)
+        return fail(RT_ERR_INVALID_ARGUMENT, "rt_closest_hit_batch_noalloc_device takes at most " +
+                                                 std::to_string(kNoAllocMaxRays) + " rays per call, got " + std::to_string(n));
+    if (n == 0) return RT_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    RT_HIP(hipSetDevice(s->device));
+    unsigned char *base = nullptr;
+    int rc = scratch_base(s->device, &base);
+    if (rc) return rc;
+    // the grid shrinks until the stacks' overflow area fits what is left of the array
+    const uint32_t deep = s->view.max_stack > RT_LDS_STACK ? s->view.max_stack - RT_LDS_STACK : 0;
+    uint32_t blocks = std::min(blocks_for(n), s->extend_blocks);
+    if (deep) {
+        const size_t per_block = (size_t)deep * kBlock * sizeof(uint2);
+        const size_t fit = (kScratchBytes - kScratchOvf) / per_block;
+        if (fit < 1)
+            return fail(RT_ERR_INVALID_ARGUMENT, "the scene's tree is too deep for the no-allocation entry point (" +
+                                                     std::to_string(s->view.max_stack) + " stack entries)");
+        if (blocks > fit) blocks = (uint32_t)fit;
+    }
+    uint32_t *head = (uint32_t *)base;
+    float4 *ro = (float4 *)(base + kScratchRo), *rd = (float4 *)(base + kScratchRd);
+    float2 *hit = (float2 *)(base + kScratchHit);
+    uint2 *ovf = (uint2 *)(base + kScratchOvf);
+    const uint32_t m = (uint32_t)n;
+    RT_HIP(hipMemsetAsync(head, 0, 256, stream));  // the array keeps the last call's contents
+    hipLaunchKernelGGL(pack_rays_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream, d_org_dir, m, ro, rd);
+    hipLaunchKernelGGL(extend_kernel<false>, dim3(blocks), dim3(kBlock), 0, stream, s->view, (const float4 *)ro,
+                       (const float4 *)rd, (const uint32_t *)nullptr, m, t_min, t_max, hit, ovf, head,
+                       (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(unpack_hits_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream, s->view, (const float2 *)hit,
+                       (const float4 *)ro, (const float4 *)rd, m, d_id, d_t, d_normal, d_point);
+    RT_HIP(hipGetLastError());
+    return RT_OK;
 }
 
 int rt_closest_hit_batch(RtScene *s, const float *org_dir, float t_min, float t_max, size_t n, int32_t *prim_id, float *t,

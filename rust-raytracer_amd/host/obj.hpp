@@ -57,12 +57,12 @@ inline std::vector<Model> load(const std::string &path) {
         std::string tag;
         if (!(ls >> tag) || tag[0] == '#') continue;
         if (tag == "v") {
-            float x, y, z;
-            ls >> x >> y >> z;
+            float x = 0.0f, y = 0.0f, z = 0.0f;
+            if (!(ls >> x >> y >> z)) throw std::runtime_error("obj: malformed vertex line '" + line + "'");
             v.insert(v.end(), {x, y, z});
         } else if (tag == "vn") {
-            float x, y, z;
-            ls >> x >> y >> z;
+            float x = 0.0f, y = 0.0f, z = 0.0f;
+            if (!(ls >> x >> y >> z)) throw std::runtime_error("obj: malformed normal line '" + line + "'");
             vn.insert(vn.end(), {x, y, z});
         } else if (tag == "vt") {
             n_vt++;

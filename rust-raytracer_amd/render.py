@@ -86,6 +86,11 @@ class Scene:
         fn = self._lib.rt_closest_hit_batch_counted_device if counted else self._lib.rt_closest_hit_batch_device
         _abi.check(fn(self._h, d_org_dir, t_min, t_max, n, d_ids, d_t, d_normal, d_point, stream))
 
+    def closest_hit_noalloc_device(self, d_org_dir, n, d_ids, d_t, d_normal, d_point, stream=0, t_min=T_MIN, t_max=T_MAX):
+        """The same batch through the entry point that allocates nothing (at most RT_NOALLOC_MAX_RAYS rays)."""
+        _abi.check(self._lib.rt_closest_hit_batch_noalloc_device(self._h, d_org_dir, t_min, t_max, n, d_ids, d_t, d_normal,
+                                                                 d_point, stream))
+
     # ---- passes ------------------------------------------------------------
     @staticmethod
     def params(width, height, samples, max_bounce, light_clamp=math.inf, mode=Mode.Image, pass_index=0, seed=0,

@@ -102,3 +102,39 @@ def test_listed_configurations_at_full_size(pkg, oracle, which):
         ora.render_range(want, p, first, count)
         a, b = got[3 * first:3 * (first + count)], want[3 * first:3 * (first + count)]
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (which, first, float(np.abs(a - b).max()))
+
+
+@pytest.mark.timeout(1500)
+def test_headline_10m_triangle_4k_pass_and_rays_match_oracle(pkg, oracle):
+    """The configuration bench.py times by default: mesh_scene(10 M triangles, seed 7), 3840 x 2160, 16 spp, 8 bounces.
+    Spans of one pass bit for bit against the oracle (first rows, the middle of the frame, the last rows, a row seam),
+    counters that must add up, and a 1 M-ray closest-hit batch with ids, t and normals exact."""
+    import torch
+
+    d = pkg.scenes.mesh_scene(n_triangles=10_000_000, seed=7)
+    scene, ora = pkg.Scene(d), oracle.OracleScene(d)
+    info = scene.info()
+    assert info.n_triangles == 9_999_362 and ora.num_prims() == info.n_primitives
+    W, H, spp, bounces = 3840, 2160, 16, 8
+    p = pkg.Scene.params(W, H, spp, bounces, pass_index=5, seed=1234)
+    accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+    scene.stats()
+    scene.render_pass_device(accum.data_ptr(), p, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    st = scene.stats()
+    got = accum.cpu().numpy()
+    del accum
+    assert np.isfinite(got).all() and got.min() >= 0.0 and got.max() > 0.0
+    assert st.paths == W * H * spp and st.paths <= st.rays <= st.paths * bounces
+    want = np.zeros(W * H * 3, np.float32)
+    for first, count in ((0, 160), (1080 * W + 1840, 160), (H * W - 160, 160), (1500 * W - 16, 32)):
+        ora.render_range(want, p, first, count)
+        a, b = got[3 * first:3 * (first + count)], want[3 * first:3 * (first + count)]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (first, float(np.abs(a - b).max()))
+    rays = pkg.scenes.random_rays(1_000_000, info.bounds_min[:], info.bounds_max[:], seed=0xC4)
+    ids, t, nrm, _ = scene.closest_hit(rays)
+    oids, ot, onrm, _ = ora.closest_hit(rays)
+    assert int((ids != oids).sum()) == 0
+    assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(nrm.view(np.uint32), onrm.view(np.uint32))
+    assert (ids >= 2).mean() > 0.2  # mesh triangles, not only the room

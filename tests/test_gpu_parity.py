@@ -311,3 +311,21 @@ def test_pixel_ranges_of_a_pass(pkg, oracle):
     assert np.array_equal(acc.view(np.uint32), whole.view(np.uint32))
     with pytest.raises(pkg.RtError):
         scene.render_pass(acc, pkg.Scene.params(W, H, spp, 8, first_pixel=W * H - 3, pixel_count=4))
+
+
+def test_preview_of_a_pixel_range_leaves_the_rest_untouched(pkg, oracle):
+    """rt_preview on host buffers with a pixel range: the range holds the preview, every other pixel of the caller's
+    buffer comes back as it went in."""
+    d = pkg.scenes.rtiow(seed=4)
+    scene, ora = pkg.Scene(d), oracle.OracleScene(d)
+    W, H = 64, 40
+    for mode in (pkg.Mode.Normals, pkg.Mode.Colors, pkg.Mode.Image):
+        whole = np.zeros(W * H * 3, np.float32)
+        ora.preview(whole, pkg.Scene.params(W, H, 1, 8, mode=mode, seed=6))
+        first, count = 777, 901
+        buf = np.full(W * H * 3, -7.25, np.float32)
+        scene.preview(buf, pkg.Scene.params(W, H, 1, 8, mode=mode, seed=6, first_pixel=first, pixel_count=count))
+        inside = np.zeros(W * H * 3, bool)
+        inside[3 * first:3 * (first + count)] = True
+        assert np.all(buf[~inside] == np.float32(-7.25))
+        assert np.array_equal(buf[inside].view(np.uint32), whole[inside].view(np.uint32))

@@ -38,26 +38,41 @@ def _luminance(a):
     return 0.2126 * a[:, 0] + 0.7152 * a[:, 1] + 0.0722 * a[:, 2]
 
 
-def test_converged_image_statistics_against_oracle_with_other_seeds(pkg, oracle):
-    """The acceptance criterion as stated for the unseeded reference: mean luminance within 1 %, per-pixel RMSE at
-    or below the oracle's own seed-to-seed RMSE.  (With equal seeds the images are bit-identical, tested elsewhere.)"""
-    d = pkg.scenes.rtiow(seed=1)
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("which", ["rtiow", "cornell", "teaset"])
+def test_converged_4096spp_image_statistics_against_oracle_with_other_seeds(pkg, oracle, which):
+    """The acceptance criterion stated for the unseeded reference, at its stated 4096 samples per pixel (64 passes of
+    64): the GPU render with seed A against oracle renders with seeds B and C.
+      mean luminance: within 1 % of each oracle render's;
+      per-pixel RMSE: at or below the oracle's own seed-to-seed noise floor, RMSE(B, C), with no slack factor.
+    The image the GPU render is held against is the oracle's best estimate of the converged frame, the mean of its
+    B and C renders.  (Against B or C alone the comparison is a coin flip by construction: A, B and C are three
+    independent draws of one estimator, so RMSE(A, B) and RMSE(B, C) have the same expectation, 2 sigma^2; against
+    the mean of two the expectation is 1.5 sigma^2, so a correct renderer passes with a margin of about 13 % and a
+    biased one does not.  With equal seeds the images are bit-identical, tested elsewhere.)"""
+    if which == "rtiow":
+        d, W, H, clamp = pkg.scenes.rtiow(seed=1), 160, 90, math.inf
+    elif which == "cornell":
+        d, W, H, clamp = pkg.scenes.cornell(), 160, 90, math.inf
+    else:
+        d, W, H, clamp = pkg.scenes.teaset(env_size=(512, 256)), 128, 72, math.inf
     scene, ora = pkg.Scene(d), oracle.OracleScene(d)
-    W, H, spp, passes = 96, 64, 64, 4
+    spp, passes = 64, 64
 
     def render(backend, seed):
         acc = np.zeros(W * H * 3, np.float32)
         for i in range(passes):
-            backend.render_pass(acc, pkg.Scene.params(W, H, spp, 8, pass_index=i, seed=seed))
+            backend.render_pass(acc, pkg.Scene.params(W, H, spp, 8, light_clamp=clamp, pass_index=i, seed=seed))
         return acc / passes
 
     gpu = render(scene, 101)
     o1, o2 = render(ora, 202), render(ora, 303)
     lg, l1, l2 = _luminance(gpu), _luminance(o1), _luminance(o2)
-    assert abs(lg.mean() - l1.mean()) <= 0.01 * l1.mean()
+    assert abs(lg.mean() - l1.mean()) <= 0.01 * l1.mean() and abs(lg.mean() - l2.mean()) <= 0.01 * l2.mean()
     floor = math.sqrt(float(np.mean((l1 - l2) ** 2)))
-    rmse = math.sqrt(float(np.mean((lg - l1) ** 2)))
-    assert rmse <= 1.1 * floor, (rmse, floor)
+    rmse = math.sqrt(float(np.mean((lg - 0.5 * (l1 + l2)) ** 2)))
+    pairwise = [math.sqrt(float(np.mean((lg - l) ** 2))) for l in (l1, l2)]
+    assert rmse <= floor, (which, rmse, floor, pairwise)
 
 
 def test_closest_hit_microbench_checks(pkg, oracle):
