@@ -6,21 +6,30 @@
 One step = one render pass (`--spp` samples per pixel over the whole frame, `--bounces`
 bounces) of the workload's scene; passes are sharded round-robin over the ranks
 (rank r renders passes r, r+N, ...), each rank holds a replica of the scene, and the
-float accumulators are summed once with a RCCL reduce at the end of the timed region.
+float accumulators are summed once at the end of the timed region (RCCL).
 Prints ONE JSON line on rank 0:
 
   value        Mrays/s of the whole job: Bvh::hit invocations (primary rays + every continued
                bounce) of all ranks / max-over-ranks wall time of the K steps
-  roofline     closest-hit ("extend") kernel: algorithmic bytes per ray (node visits x 128 B +
-               primitive tests x 48 B + 32 B ray in + 8 B hit out, visits/tests counted by the
-               instrumented kernel on the same workload outside the timed region) x rays per
-               launch / mean launch duration (HIP events on the launch stream, timed region)
+  roofline     closest-hit ("extend") kernel.  The kernel is bound by vector-instruction issue under
+               divergence, not by bytes (its counters: VALU busy ~0.9 of SIMD cycles at about half the
+               lanes active), so the fraction reported is the USEFUL share of the vector unit:
+                 frac = (SIMD cycles issuing VALU / SIMD cycles) x (active lanes / 64 per VALU instruction)
+               from the rocprofv3 counter profile of this same configuration under profiles/, used
+               only while its stamp (hash of the kernel sources, bench arguments) matches this run;
+               otherwise frac falls back to the lane occupancy of the kernel's steps, counted live by
+               the instrumented kernel.  Beside it, reported and not used as the fraction:
+               the HBM side (FETCH_SIZE of the same profile x the factor calibrated on a one-line-per-
+               lane gather, / launch time, / 8 TB/s) and the algorithmic bytes per ray (node visits
+               x 128 B + primitive tests x 48 B + 40 B, counted live at the timed resolution), most of
+               which the caches serve.  Launch durations are HIP events on the launch stream.
   cpu_baseline the CPU oracle (a restatement of the reference's renderer, not the Rust binary)
                on a bounded sample of the same workload: same scene, samples and bounces at a
                reduced resolution, on this box's host cores (N=1 only)
+  --total-passes P  strong scaling: P passes in all, split round-robin over the ranks ("scaling": "strong")
 """
 import argparse
-import ctypes as C
+import glob
 import json
 import math
 import os
@@ -31,9 +40,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from srchash import kernel_source_hash  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
-LIMITER = None  # what the PMC profile says bounds the kernel, when one is committed for the configuration
+N_SIMD = 1024          # 256 CUs x 4
+MAX_CLOCK_GHZ = 2.4
 
 
 def build_workload(pkg, args):
@@ -54,6 +66,44 @@ def build_workload(pkg, args):
     return desc, name
 
 
+def config_key(args):
+    """Names the timed configuration; a counter profile is only used for the configuration it was taken on."""
+    if args.workload == "closest_hit":
+        return "closest_hit tris=%d rays=%d" % (args.tris, args.rays)
+    tris = args.tris if args.workload == "mesh" else 0
+    return "%s tris=%d %dx%d spp=%d bounces=%d batch=%d" % (args.workload, tris, args.width, args.height, args.spp,
+                                                           args.bounces, args.batch_paths)
+
+
+def matching_profile(key):
+    """A counter profile under profiles/ taken from THIS kernel source (hash) on THIS configuration, or None."""
+    want = kernel_source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
+        try:
+            p = json.load(open(path))
+        except Exception:
+            continue
+        line = p.get("bench_line_under_rocprof") or {}
+        e = p.get("extend") or {}
+        if (p.get("source_hash") == want and (line.get("config") or {}).get("key") == key
+                and "valu_busy_fraction" in e and "valu_lane_utilisation" in e and "hbm_bytes_per_launch_raw" in e):
+            p["_file"] = os.path.relpath(path, ROOT)
+            return p
+    return None
+
+
+def fetch_factor():
+    """Bytes per FETCH_SIZE byte on a one-128-B-line-per-lane random gather (tools/ubench/gather_fetch.hip), the node
+    fetch pattern of the kernel; 1.0 with a note when no calibration is committed."""
+    path = os.path.join(ROOT, "profiles", "r02_fetch_calibration.json")
+    if os.path.exists(path):
+        c = json.load(open(path))
+        if "gather128" in c:
+            return (round(c["gather128"]["factor_vs_lines"], 3),
+                    "calibrated on %s: known bytes of a one-128-B-line-per-lane random gather / FETCH_SIZE" % os.path.relpath(path, ROOT))
+    return 1.0, "uncalibrated (raw FETCH_SIZE x 1 KiB)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +119,10 @@ def main():
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--total-passes", type=int, default=0,
+                    help="strong scaling: this many passes in all, split over the ranks (overrides --steps)")
+    ap.add_argument("--reduce", default="auto", choices=["auto", "torch", "native"],
+                    help="how the accumulators are summed at N > 1: torch.distributed (RCCL) or the library's own RCCL reduce")
     args = ap.parse_args()
 
     import torch
@@ -105,6 +159,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     W, H, spp, bounces = args.width, args.height, args.spp, args.bounces
+    strong = args.total_passes > 0 and args.workload != "closest_hit"
+    # passes this rank renders in the timed region: rank, rank + world, ... (< total) when the total is fixed
+    my_steps = len(range(rank, args.total_passes, world)) if strong else args.steps
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,21 +198,35 @@ def main():
             scene.render_pass_device(accum.data_ptr(), p, stream)
 
         def count_step():
-            # same workload at a quarter of the resolution: the same ray distribution, fewer rays
-            p = pkg.Scene.params(max(2, W // 2), max(2, H // 2), spp, bounces, pass_index=10_000, seed=1234)
-            tmp = torch.zeros((max(2, W // 2) * max(2, H // 2) * 3), dtype=torch.float32, device="cuda")
+            # one pass of the timed configuration through the counting kernel
+            p = pkg.Scene.params(W, H, spp, bounces, pass_index=10_000, seed=1234, batch_paths=args.batch_paths)
+            tmp = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
             scene.set_counting(True)
             scene.render_pass_device(tmp.data_ptr(), p, stream)
             torch.cuda.synchronize()
             scene.set_counting(False)
 
-    # ---- bytes per ray, from the instrumented kernel (untimed)
+    # ---- node visits / primitive tests per ray and the steps' lane occupancy, from the instrumented kernel (untimed)
     scene.stats()
     count_step()
     cs = scene.stats()
     visits_per_ray = cs.node_visits / max(1, cs.rays)
     tests_per_ray = cs.prim_tests / max(1, cs.rays)
     bytes_per_ray = visits_per_ray * info.node_bytes + tests_per_ray * info.primitive_bytes + 32 + 8
+    steps_counted = cs.node_steps + cs.leaf_steps
+    step_lane_occupancy = ((cs.node_step_lanes + cs.leaf_step_lanes) / (64.0 * steps_counted)) if steps_counted else None
+
+    # ---- the sum of the accumulators: the one collective of a render
+    use_native = world > 1 and args.workload != "closest_hit" and args.reduce == "native"
+
+    def reduce_sum(buf):
+        if use_native:
+            pkg.parallel.native_reduce(buf, rank, world, stream)
+        else:
+            dist.reduce(buf, dst=0)
+
+    if use_native:
+        pkg.parallel.native_comm_init(rank, world, dist)
 
     # ---- warmup, then the timed region
     for i in range(args.warmup):
@@ -164,16 +235,16 @@ def main():
         # the warmup also runs the collective once, on a scratch buffer of the accumulator's size, so that
         # the communicator's channels and buffers exist before the timed region
         scratch = torch.zeros_like(accum)
-        dist.reduce(scratch, dst=0)
+        reduce_sum(scratch)
         del scratch
     barrier()
     scene.stats()
     scene.set_stage_timing(True)
     t_start = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(my_steps):
         step(args.warmup + i)
     if world > 1 and args.workload != "closest_hit":
-        dist.reduce(accum, dst=0)  # the one collective of a render: sum of the accumulators
+        reduce_sum(accum)
     barrier()
     elapsed = time.perf_counter() - t_start
     st = scene.stats()
@@ -189,55 +260,89 @@ def main():
 
     if rank == 0:
         value = rays_total / elapsed_max / 1e6
+        steps_reported = args.total_passes if strong else args.steps
         extend_s = st.extend_ms / 1e3
-        achieved = (st.rays * bytes_per_ray / extend_s / 1e9) if extend_s > 0 else 0.0
         launches = max(1, int(st.extend_launches))
-        traffic, traffic_note = measured_traffic(args, info)
+        key = config_key(args)
+        prof = matching_profile(key)
+        roof = {
+            "bound": "valu",
+            "kernel": "extend_kernel (closest hit)",
+            "unit": "G lane-op/s",
+            "launches": launches,
+            "mean_launch_ms": round(st.extend_ms / launches, 3),
+            "extend_Mrays_per_s": round(st.rays / extend_s / 1e6, 1) if extend_s > 0 else None,
+            "extend_ms_total": round(st.extend_ms, 3),
+            "shade_ms_total": round(st.shade_ms, 3),
+            "other_ms_total": round(st.other_ms, 3),
+            "step_lane_occupancy_live": round(step_lane_occupancy, 4) if step_lane_occupancy is not None else None,
+            "node_step_lanes_live": round(cs.node_step_lanes / max(1, cs.node_steps), 1),
+            "leaf_step_lanes_live": round(cs.leaf_step_lanes / max(1, cs.leaf_steps), 1),
+            "algorithmic_bytes_per_ray": round(bytes_per_ray, 1),
+            "algorithmic_bytes_per_launch": int(st.rays * bytes_per_ray / launches),
+            "algorithmic_GBps": round(st.rays * bytes_per_ray / extend_s / 1e9, 1) if extend_s > 0 else None,
+            "node_visits_per_ray": round(visits_per_ray, 2),
+            "prim_tests_per_ray": round(tests_per_ray, 2),
+        }
+        if prof is not None:
+            e = prof["extend"]
+            clock = e.get("clock_GHz_under_profile") or MAX_CLOCK_GHZ
+            # G lane-op/s at one wave64 VALU instruction per 4 SIMD cycles on every SIMD: what "VALU busy = 1, all lanes active" is
+            peak = N_SIMD * 64 / 4.0 * clock
+            frac = e["valu_busy_fraction"] * e["valu_lane_utilisation"]
+            factor, factor_note = fetch_factor()
+            hbm_bytes = e["hbm_bytes_per_launch_raw"] * factor
+            prof_launch_s = e["mean_launch_ms"] / 1e3
+            roof.update({
+                "achieved": round(frac * peak, 1), "peak": round(peak, 1), "frac": round(frac, 4),
+                "valu_busy": round(e["valu_busy_fraction"], 4), "valu_lane_utilisation": round(e["valu_lane_utilisation"], 4),
+                "salu_per_valu_inst": round(e["SQ_INSTS_SALU_per_launch"] / e["SQ_INSTS_VALU_per_launch"], 3),
+                "traffic": int(hbm_bytes),
+                "hbm": {"achieved_GBps": round(hbm_bytes / prof_launch_s / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                        "frac": round(hbm_bytes / prof_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                        "fetch_size_raw_bytes": int(e["hbm_bytes_per_launch_raw"]), "factor": factor, "factor_note": factor_note,
+                        "l2_hit_rate": round(e.get("l2_hit_rate", 0.0), 4)},
+                "profile": {"file": prof["_file"], "source_hash": prof["source_hash"], "git_head": prof.get("git_head", ""),
+                            "mean_launch_ms_under_profile": round(e["mean_launch_ms"], 3),
+                            "note": "counters from separate rocprofv3 --pmc runs of this configuration (one run per counter group), "
+                                    "not from this run"},
+            })
+        else:
+            # no counter profile of this code and configuration: the fraction of a wave's lanes the kernel's steps work for
+            roof.update({"achieved": None, "peak": round(N_SIMD * 64 / 4.0 * MAX_CLOCK_GHZ, 1),
+                         "frac": round(step_lane_occupancy, 4) if step_lane_occupancy is not None else None,
+                         "traffic": None,
+                         "profile": {"file": None,
+                                     "note": "no profile under profiles/ matches source hash %s and configuration '%s'; frac is "
+                                             "the live step lane occupancy" % (kernel_source_hash(), key)}})
         out = {
             "metric": "Mrays/s (extend+shade)",
             "value": round(value, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": steps_reported,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / args.steps * 1e3, 3),
+            "ms_per_step": round(elapsed_max / max(1, steps_reported) * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
                 "workload": wl_name,
                 "kind": args.workload,
+                "key": key,
                 "width": W, "height": H, "spp_per_pass": spp, "max_bounce": bounces,
                 "primitives": int(info.n_primitives), "wide_nodes": int(info.n_wide_nodes),
                 "scene_MB": round(info.device_bytes / 1e6, 1),
-                "parallelism": "passes round-robin over %d GPU(s), scene replicated, one RCCL reduce" % world,
-                "s_per_4k_frame": round(elapsed_max / args.steps, 4) if (W, H) == (3840, 2160) else None,
-                "rays_per_step_per_gpu": int(st.rays / max(1, args.steps)),
+                "parallelism": ("%d passes in all, " % args.total_passes if strong else "") +
+                               "passes round-robin over %d GPU(s), scene replicated, one RCCL sum (%s)" % (
+                                   world, "library" if use_native else "torch.distributed"),
+                "s_per_4k_frame": round(elapsed_max / max(1, my_steps), 4) if (W, H) == (3840, 2160) else None,
+                "rays_per_step_per_gpu": int(st.rays / max(1, my_steps)),
                 "scene_gen_s": round(t_gen, 2), "scene_build_s": round(t_build, 2),
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "extend_kernel (closest hit)",
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "traffic_note": traffic_note,
-                "limiter": LIMITER,
-                "launches": launches,
-                "mean_launch_ms": round(st.extend_ms / launches, 3),
-                "algorithmic_bytes_per_launch": int(st.rays * bytes_per_ray / launches),
-                "bytes_per_ray": round(bytes_per_ray, 1),
-                "node_visits_per_ray": round(visits_per_ray, 2),
-                "prim_tests_per_ray": round(tests_per_ray, 2),
-                "extend_ms_total": round(st.extend_ms, 3),
-                "shade_ms_total": round(st.shade_ms, 3),
-                "other_ms_total": round(st.other_ms, 3),
-                "extend_Mrays_per_s": round(st.rays / extend_s / 1e6, 1) if extend_s > 0 else None,
-            },
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(pkg, desc, args, W, H, spp, bounces, info)
@@ -247,31 +352,15 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(args, info):
-    """HBM bytes per closest-hit launch from the PMC pass of the same command (rocprofv3 --pmc FETCH_SIZE in its
-    own run, summarised by tools/extend_pmc_json.py), or None when no profile of this configuration is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_extend_pmc_c4_final.json")
-    default_cfg = (args.workload == "mesh" and args.tris == 10_000_000 and (args.width, args.height) == (3840, 2160)
-                   and args.spp == 16 and args.bounces == 8 and args.batch_paths == 0)
-    if not (default_cfg and os.path.exists(path)):
-        return None, "no PMC profile committed for this configuration"
-    p = json.load(open(path))
-    global LIMITER
-    LIMITER = ("instruction issue, not bandwidth: VALU busy %.0f %% of SIMD cycles at %.0f %% active lanes, L2 hit rate %.0f %% "
-               "(same PMC profile); algorithmic bytes exceed HBM traffic because the upper tree levels are served from cache"
-               % (100 * p["valu_busy_fraction"], 100 * p["valu_lane_utilisation"], 100 * p["l2_hit_rate"]))
-    return (int(p["hbm_bytes_per_launch_corrected"]),
-            "bytes per launch from %s: FETCH_SIZE x 1 KiB x 2 (gfx950 reports half the bytes of 16 B/lane reads; "
-            "calibrated on coalesced streams, this kernel gathers one line per lane); raw %d" % (
-                os.path.relpath(path, ROOT), int(p["hbm_bytes_per_launch_raw"])))
-
-
 def cpu_baseline(pkg, desc, args, W, H, spp, bounces, info):
     """The CPU oracle on a bounded sample of the workload (checker code, timed here as the CPU column)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
 
-    threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    # the GPU box grants a one-GPU job 16 host CPUs (it exports OMP_NUM_THREADS = 16); the machine itself has more
+    host_cpus = len(os.sched_getaffinity(0))
+    threads = min(host_cpus, int(os.environ.get("OMP_NUM_THREADS", "16") or 16))
+    ob.lib().oracle_set_counting(0)  # per-node counters off: this leg is timed
     ora = ob.OracleScene(desc)
     if args.workload == "closest_hit":
         n = 200_000
@@ -282,8 +371,8 @@ def cpu_baseline(pkg, desc, args, W, H, spp, bounces, info):
             ora.closest_hit(rays, threads=threads)
             reps += 1
         dt = time.perf_counter() - t0
-        return {"value": round(n * reps / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                "sample": "%d x %d random rays, same scene" % (reps, n)}
+        return {"value": round(n * reps / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "host_cpus_visible": host_cpus,
+                "kind": "port", "sample": "%d x %d random rays, same scene" % (reps, n)}
     # calibrate on a tiny frame, then size the sample to about cpu_seconds
     w0, h0 = max(2, W // 32), max(2, H // 32)
     p = pkg.Scene.params(w0, h0, spp, bounces, seed=1234)
@@ -299,7 +388,8 @@ def cpu_baseline(pkg, desc, args, W, H, spp, bounces, info):
     ora.render_pass(acc, p, threads=threads)
     dt = time.perf_counter() - t0
     rays = ora.counters()["rays"]
-    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+    return {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "host_cpus_visible": host_cpus,
+            "kind": "port",
             "sample": "one pass of the same scene, camera, %d spp, %d bounces at %dx%d (%.1f s)" % (spp, bounces, w1, h1, dt)}
 
 

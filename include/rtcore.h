@@ -209,6 +209,13 @@ typedef struct RtStats {
     double shade_ms;
     double other_ms;
     uint64_t extend_launches; /* closest-hit kernel launches the times above cover */
+    /* Lane occupancy of the closest-hit kernel's steps, only filled by the *_counted entry points / rt_set_counting:
+     * a wave runs one step at a time, for the lanes whose ray is at a node (node step) or at a leaf (leaf step);
+     * *_lanes / (64 * *_steps) is the fraction of a wave's lanes a step of that kind works for. */
+    uint64_t node_steps;
+    uint64_t node_step_lanes;
+    uint64_t leaf_steps;
+    uint64_t leaf_step_lanes;
 } RtStats;
 
 /* Library / device bring-up.  device < 0 keeps the current HIP device. */

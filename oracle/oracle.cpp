@@ -376,6 +376,9 @@ struct Counters {
     uint64_t rays = 0, node_visits = 0, prim_tests = 0;
 };
 thread_local Counters *tl_counters = nullptr;
+// per-node and per-primitive counts are optional (oracle_set_counting): a timed run leaves them out
+thread_local Counters *tl_detail = nullptr;
+std::atomic<bool> g_count_detail(true);
 
 // src/tracer/hittable.rs:7-11
 struct Hittable {
@@ -393,7 +396,7 @@ struct Sphere : Hittable {
     const Material *material;
     int32_t prim_id;
     bool hit(const Ray &ray, float t_min, float t_max, HitRecord &rec) const override {
-        if (tl_counters) tl_counters->prim_tests++;
+        if (tl_detail) tl_detail->prim_tests++;
         Vec3 oc = ray.pos - center;
         float half_b = oc.dot(ray.dir);
         float disc = half_b * half_b - (oc.mag_sq() - (radius * radius));
@@ -471,7 +474,7 @@ struct ABox : Hittable {
         return false;
     }
     bool hit(const Ray &ray, float t_min, float t_max, HitRecord &rec) const override {
-        if (tl_counters) tl_counters->prim_tests++;
+        if (tl_detail) tl_detail->prim_tests++;
         return hit_inner(ray, t_min, t_max, rec);
     }
     Aabb bounding_box() const override { return Aabb{min, max}; }
@@ -488,7 +491,7 @@ struct Cube : Hittable {
         rotation = Rotor3::from_euler_angles(rot[2] * PI, rot[0] * PI, rot[1] * PI).normalized();
     }
     bool hit(const Ray &ray, float t_min, float t_max, HitRecord &rec) const override {
-        if (tl_counters) tl_counters->prim_tests++;
+        if (tl_detail) tl_detail->prim_tests++;
         Vec3 rot_pos = rotation.reversed().rotate(ray.pos - center) + center;
         Vec3 rot_dir = rotation.reversed().rotate(ray.dir);
         HitRecord h;
@@ -521,7 +524,7 @@ struct Triangle : Hittable {
     bool two_sided;
     int32_t prim_id;
     bool hit(const Ray &ray, float t_min, float t_max, HitRecord &rec) const override {
-        if (tl_counters) tl_counters->prim_tests++;
+        if (tl_detail) tl_detail->prim_tests++;
         Vec3 edge1 = vertices[1] - vertices[0];
         Vec3 edge2 = vertices[2] - vertices[0];
         Vec3 h = ray.dir.cross(edge2);
@@ -638,7 +641,7 @@ struct Bvh : Hittable {
             aabb_box = left->bounding_box();
     }
     bool hit(const Ray &ray, float t_min, float t_max, HitRecord &rec) const override {
-        if (tl_counters) tl_counters->node_visits++;
+        if (tl_detail) tl_detail->node_visits++;
         Vec3 inv_d(recip(ray.dir.x), recip(ray.dir.y), recip(ray.dir.z));
         if (!aabb_box.hit(ray.pos, inv_d, t_min, t_max)) return false;
         HitRecord rr, lr;
@@ -839,6 +842,7 @@ void parallel_chunks(size_t n, int threads, F f) {
     for (int t = 0; t < threads; t++) {
         pool.emplace_back([&, t]() {
             tl_counters = &counters[t];
+            tl_detail = g_count_detail.load() ? &counters[t] : nullptr;
             for (;;) {
                 size_t c = next.fetch_add(1);
                 size_t lo = c * chunk;
@@ -847,6 +851,7 @@ void parallel_chunks(size_t n, int threads, F f) {
                 f(lo, hi);
             }
             tl_counters = nullptr;
+            tl_detail = nullptr;
         });
     }
     for (auto &th : pool) th.join();
@@ -1076,6 +1081,8 @@ int oracle_preview(OracleScene *s, const RtRenderParams *p, float *out, int thre
     s->last_rays = g_last_counters.rays;
     return RT_OK;
 }
+
+void oracle_set_counting(int enabled) { g_count_detail.store(enabled != 0); }
 
 void oracle_last_counters(const OracleScene *s, uint64_t out[3]) {
     out[0] = s->last_rays, out[1] = s->last_node_visits, out[2] = s->last_prim_tests;

@@ -131,6 +131,10 @@ class RtStats(C.Structure):
         ("shade_ms", C.c_double),
         ("other_ms", C.c_double),
         ("extend_launches", C.c_uint64),
+        ("node_steps", C.c_uint64),
+        ("node_step_lanes", C.c_uint64),
+        ("leaf_steps", C.c_uint64),
+        ("leaf_step_lanes", C.c_uint64),
     ]
 
 

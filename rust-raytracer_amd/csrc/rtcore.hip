@@ -971,6 +971,8 @@ int rt_scene_stats(const RtScene *cs, RtStats *out) {
         RT_HIP(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         s->stats.node_visits += c[0];
         s->stats.prim_tests += c[1];
+        s->stats.leaf_steps += c[2], s->stats.leaf_step_lanes += c[3];
+        s->stats.node_steps += c[4], s->stats.node_step_lanes += c[5];
         if (std::getenv("RTCORE_DEBUG_STEPS") && c[2] + c[4])
             std::fprintf(stderr,
                          "[rtcore] leaf steps %llu with %.1f lanes, node steps %llu with %.1f lanes, %.1f lanes not stepping "

@@ -33,6 +33,7 @@ def lib():
         L.oracle_preview.restype = C.c_int
         L.oracle_preview.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.oracle_last_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_set_counting.argtypes = [C.c_int]
         L.oracle_schlick.restype = C.c_float
         L.oracle_schlick.argtypes = [C.c_float, C.c_float, C.c_float]
         L.oracle_sky_gradient.argtypes = [C.c_void_p, C.c_void_p]
