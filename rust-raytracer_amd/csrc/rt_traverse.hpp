@@ -312,29 +312,18 @@ RT_DEV void traversal_leaf_step(const RtSceneView &sc, Traversal &tr, float t_mi
     }
 }
 
-// tr.entry is a node: tests its four child boxes, pushes the far hits and continues with the
-// nearest.  Returns true when no child was hit: the lane then wants the next stack entry.
-template <bool COUNT>
-RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
-    const char *__restrict__ nodes = (const char *)sc.nodes;
-    const Ray &ray = tr.ray;
-    const F3 inv = tr.inv;
-    // 32-bit byte offsets from the (uniform) node array base
-    const uint32_t base = tr.entry * (RT_NODE_FLOAT4S * 16u);
-    const float4 nx4 = *(const float4 *)(nodes + (base + 0u));
-    const float4 ny4 = *(const float4 *)(nodes + (base + 16u));
-    const float4 nz4 = *(const float4 *)(nodes + (base + 32u));
-    const float4 fx4 = *(const float4 *)(nodes + (base + 48u));
-    const float4 fy4 = *(const float4 *)(nodes + (base + 64u));
-    const float4 fz4 = *(const float4 *)(nodes + (base + 80u));
-    const float4 cwf = *(const float4 *)(nodes + (base + 96u));
-    if (COUNT) (*visits)++;
-    uint32_t cw[4] = {__float_as_uint(cwf.x), __float_as_uint(cwf.y), __float_as_uint(cwf.z), __float_as_uint(cwf.w)};
+// The four child boxes of a wide node against a ray: the slab test of src/tracer/cube.rs:163-171 per child, then the
+// hit children sorted by entry distance.  In: the node's seven 16-byte words.  Out: key[0..nh) ascending entry
+// distances with their child words in cw[0..nh); returns nh.
+RT_DEV int node_children(const float4 nx4, const float4 ny4, const float4 nz4, const float4 fx4, const float4 fy4,
+                         const float4 fz4, const float4 cwf, const F3 o, const F3 inv, float t_min, float t_best,
+                         float key[4], uint32_t cw[4]) {
+    cw[0] = __float_as_uint(cwf.x), cw[1] = __float_as_uint(cwf.y), cw[2] = __float_as_uint(cwf.z), cw[3] = __float_as_uint(cwf.w);
     // the reference's t0 = (min - o) * inv, t1 = (max - o) * inv (src/tracer/cube.rs:164-165) for two
     // children at a time: gfx950 subtracts and multiplies two floats per instruction
     // (v_pk_add_f32 / v_pk_mul_f32, IEEE results, no contraction), min / max have no packed form.
     typedef float Pair __attribute__((ext_vector_type(2)));
-    const Pair ox = {ray.o.x, ray.o.x}, oy = {ray.o.y, ray.o.y}, oz = {ray.o.z, ray.o.z};
+    const Pair ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
     const Pair ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
     const Pair t0x[2] = {(Pair{nx4.x, nx4.y} - ox) * ix, (Pair{nx4.z, nx4.w} - ox) * ix};
     const Pair t1x[2] = {(Pair{fx4.x, fx4.y} - ox) * ix, (Pair{fx4.z, fx4.w} - ox) * ix};
@@ -342,13 +331,10 @@ RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st,
     const Pair t1y[2] = {(Pair{fy4.x, fy4.y} - oy) * iy, (Pair{fy4.z, fy4.w} - oy) * iy};
     const Pair t0z[2] = {(Pair{nz4.x, nz4.y} - oz) * iz, (Pair{nz4.z, nz4.w} - oz) * iz};
     const Pair t1z[2] = {(Pair{fz4.x, fz4.y} - oz) * iz, (Pair{fz4.z, fz4.w} - oz) * iz};
-    float key[4];
     const float kInf = __int_as_float(0x7f800000);
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         // per-axis min / max of the two plane distances and the interval test (src/tracer/cube.rs:166-170).
-        // Loading the planes pre-ordered by the ray's direction signs would save the six min/max, but
-        // the three extra per-ray registers spill at 6 waves/SIMD and the kernel ran 13 % slower.
         const float ax0 = t0x[c >> 1][c & 1], ax1 = t1x[c >> 1][c & 1];
         const float ay0 = t0y[c >> 1][c & 1], ay1 = t1y[c >> 1][c & 1];
         const float az0 = t0z[c >> 1][c & 1], az1 = t1z[c >> 1][c & 1];
@@ -356,7 +342,7 @@ RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st,
         float nyv = fminf(ay0, ay1), fyv = fmaxf(ay0, ay1);
         float nzv = fminf(az0, az1), fzv = fmaxf(az0, az1);
         float tn = fmaxf(fmaxf(fmaxf(nxv, nyv), nzv), t_min);
-        float tf = fminf(fminf(fminf(fxv, fyv), fzv), tr.best.t);
+        float tf = fminf(fminf(fminf(fxv, fyv), fzv), t_best);
         bool hit = (cw[c] != RT_CHILD_NONE) && (tn <= tf);
         key[c] = hit ? tn : kInf;
     }
@@ -372,8 +358,28 @@ RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st,
     }
     RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
+    return (int)(key[0] < kInf) + (int)(key[1] < kInf) + (int)(key[2] < kInf) + (int)(key[3] < kInf);
+}
+
+// tr.entry is a node: tests its four child boxes, pushes the far hits and continues with the
+// nearest.  Returns true when no child was hit: the lane then wants the next stack entry.
+template <bool COUNT>
+RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
+    const char *__restrict__ nodes = (const char *)sc.nodes;
+    // 32-bit byte offsets from the (uniform) node array base
+    const uint32_t base = tr.entry * (RT_NODE_FLOAT4S * 16u);
+    const float4 nx4 = *(const float4 *)(nodes + (base + 0u));
+    const float4 ny4 = *(const float4 *)(nodes + (base + 16u));
+    const float4 nz4 = *(const float4 *)(nodes + (base + 32u));
+    const float4 fx4 = *(const float4 *)(nodes + (base + 48u));
+    const float4 fy4 = *(const float4 *)(nodes + (base + 64u));
+    const float4 fz4 = *(const float4 *)(nodes + (base + 80u));
+    const float4 cwf = *(const float4 *)(nodes + (base + 96u));
+    if (COUNT) (*visits)++;
+    float key[4];
+    uint32_t cw[4];
     // hits are key[0 .. nh); the nearest continues, the others go on the stack far to near
-    const int nh = (int)(key[0] < kInf) + (int)(key[1] < kInf) + (int)(key[2] < kInf) + (int)(key[3] < kInf);
+    const int nh = node_children(nx4, ny4, nz4, fx4, fy4, fz4, cwf, tr.ray.o, tr.inv, t_min, tr.best.t, key, cw);
     if (nh > 1) {
         const int top = st.sp + nh - 1;
         if (top <= RT_LDS_STACK) {

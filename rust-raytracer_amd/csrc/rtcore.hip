@@ -30,6 +30,7 @@
 #include "../../include/rtcore.h"
 #include "rt_device.hpp"
 #include "rt_traverse.hpp"
+#include "rt_pool.hpp"
 #include "scene_build.hpp"
 
 using namespace rtd;
@@ -238,6 +239,44 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         {
             dbg[7] = (unsigned long long)(clock64() - loop_t0);
             for (int k = 0; k < 8; k++) atomicAdd(&counters[2 + k], dbg[k]);
+        }
+    }
+}
+
+// The pooled form of the extend stage (rt_pool.hpp): one wave per block, its pool of rays in LDS.
+#ifndef RT_POOL_WAVES
+#define RT_POOL_WAVES 2
+#endif
+template <bool COUNT>
+__global__ void __launch_bounds__(64, RT_POOL_WAVES)
+    extend_pool_kernel(RtSceneView sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
+                       const uint32_t *__restrict__ count_ptr, uint32_t n_fixed, float t_min, float t_max,
+                       float2 *__restrict__ hit, uint2 *ovf, uint32_t *head, unsigned long long *counters) {
+    __shared__ PoolLds L;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < kPoolSlots; i += 64u) L.q[Q_FREE][i] = (uint8_t)i;
+    PoolWave<COUNT> w(L, sc);
+    for (int k = 0; k < 4; k++) w.Q.tail[k] = 0u, w.Q.count[k] = 0u;
+    w.Q.tail[Q_FREE] = kPoolSlots, w.Q.count[Q_FREE] = kPoolSlots;
+    w.ro = ro, w.rd = rd, w.hit = hit, w.head = head;
+    w.n_rays = count_ptr ? *count_ptr : n_fixed;
+    w.t_min = t_min, w.t_max = t_max, w.lane = lane;
+    w.chunk_next = 0u, w.chunk_end = 0u, w.no_more = false;
+    const uint32_t deep = sc.max_stack > kPoolStack ? sc.max_stack - kPoolStack : 0u;
+    w.ovf = ovf + (size_t)blockIdx.x * deep * kPoolSlots;
+    if (COUNT) {
+        w.cnt.visits = 0u, w.cnt.tests = 0u;
+        for (int k = 0; k < 4; k++) w.cnt.steps[k] = 0ull, w.cnt.lanes[k] = 0ull;
+    }
+    w.run();
+    if (COUNT) {
+        atomicAdd(&counters[0], (unsigned long long)w.cnt.visits);
+        atomicAdd(&counters[1], (unsigned long long)w.cnt.tests);
+        if (lane == 0) {
+            atomicAdd(&counters[2], w.cnt.steps[Q_LEAF]), atomicAdd(&counters[3], w.cnt.lanes[Q_LEAF]);
+            atomicAdd(&counters[4], w.cnt.steps[Q_NODE]), atomicAdd(&counters[5], w.cnt.lanes[Q_NODE]);
+            atomicAdd(&counters[10], w.cnt.steps[Q_POP]), atomicAdd(&counters[11], w.cnt.lanes[Q_POP]);
+            atomicAdd(&counters[12], w.cnt.steps[K_REFILL]), atomicAdd(&counters[13], w.cnt.lanes[K_REFILL]);
         }
     }
 }
@@ -572,6 +611,8 @@ struct RtScene {
     uint64_t work_paths = 0;
     uint64_t paths_in_flight = 0;  // default batch size, fixed at the first call that needs it
     uint32_t extend_blocks = 0;
+    bool pooled = false;         // which form of the extend stage runs (RTCORE_EXTEND=pool|wave)
+    uint32_t pool_blocks = 0;    // resident one-wave blocks of the pooled form
     bool timing = false;
     bool counting = false;
     std::vector<TimedSpan> spans;
@@ -595,8 +636,9 @@ int ensure_work(RtScene *s, uint64_t paths) {
     if (paths <= s->work_paths && s->extend_blocks) return RT_OK;
     int rc;
     for (int k = 0; k < 2; k++) {
-        if ((rc = s->st_o[k].ensure(paths * 16))) return rc;
-        if ((rc = s->st_d[k].ensure(paths * 16))) return rc;
+        // (128 spare bytes: the pooled extend stage requests seven 16-byte words from every record it touches)
+        if ((rc = s->st_o[k].ensure(paths * 16 + 128))) return rc;
+        if ((rc = s->st_d[k].ensure(paths * 16 + 128))) return rc;
         if ((rc = s->st_thr[k].ensure(paths * 16))) return rc;
     }
     if ((rc = s->hit_a.ensure(paths * 8))) return rc;
@@ -610,10 +652,21 @@ int ensure_work(RtScene *s, uint64_t paths) {
         if ((rc = s->counters.ensure(128))) return rc;
         RT_HIP(hipMemset(s->counters.p, 0, 128));
     }
+    if (s->pooled && !s->pool_blocks) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, extend_pool_kernel<false>, 64, 0) != hipSuccess || per_cu < 1)
+            per_cu = 4;
+        s->pool_blocks = (uint32_t)s->n_cus * (uint32_t)per_cu;
+    }
     if (!s->extend_blocks) s->extend_blocks = resident_extend_blocks(s->n_cus);
     uint32_t deep = s->view.max_stack > RT_LDS_STACK ? s->view.max_stack - RT_LDS_STACK : 0;
-    if (deep) {
-        if ((rc = s->ovf.ensure((size_t)deep * s->extend_blocks * kBlock * sizeof(uint2)))) return rc;
+    size_t ovf_bytes = (size_t)deep * s->extend_blocks * kBlock * sizeof(uint2);
+    if (s->pooled) {
+        const uint32_t pdeep = s->view.max_stack > kPoolStack ? s->view.max_stack - kPoolStack : 0;
+        ovf_bytes = std::max(ovf_bytes, (size_t)pdeep * s->pool_blocks * kPoolSlots * sizeof(uint2));
+    }
+    if (ovf_bytes) {
+        if ((rc = s->ovf.ensure(ovf_bytes))) return rc;
     }
     s->work_paths = paths;
     return RT_OK;
@@ -657,6 +710,17 @@ int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4
     if (n_upper == 0) return RT_OK;
     uint32_t blocks = std::min(blocks_for(n_upper), s->extend_blocks);
     StageTimer tm(s, stream, 0);
+    if (s->pooled) {
+        const uint32_t pblocks = std::min((n_upper + 63u) / 64u, s->pool_blocks);
+        if (counted)
+            hipLaunchKernelGGL(extend_pool_kernel<true>, dim3(pblocks), dim3(64), 0, stream, s->view, ro, rd, count_ptr, n_upper,
+                               t_min, t_max, (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head, (unsigned long long *)s->counters.p);
+        else
+            hipLaunchKernelGGL(extend_pool_kernel<false>, dim3(pblocks), dim3(64), 0, stream, s->view, ro, rd, count_ptr, n_upper,
+                               t_min, t_max, (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head, (unsigned long long *)s->counters.p);
+        RT_HIP(hipGetLastError());
+        return RT_OK;
+    }
     if (counted)
         hipLaunchKernelGGL(extend_kernel<true>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
                            n_upper, t_min, t_max, (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head,
@@ -860,11 +924,12 @@ int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
     RT_HIP(hipGetDeviceProperties(&prop, s->device));
     s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     s->extend_blocks = resident_extend_blocks(s->n_cus);
+    if (const char *e = std::getenv("RTCORE_EXTEND")) s->pooled = std::string(e) == "pool";
 
     rtcore::HostScene &h = s->host;
     auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
         if (bytes == 0) return RT_OK;
-        int r = b.ensure(bytes);
+        int r = b.ensure(bytes + 128);  // 128 spare bytes, see ensure_work
         if (r) return r;
         RT_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
         s->device_bytes += bytes;
@@ -967,7 +1032,7 @@ int rt_scene_stats(const RtScene *cs, RtStats *out) {
         RT_HIP(hipMemset(s->totals.p, 0, 64));
     }
     if (s->counters.p) {
-        unsigned long long c[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         RT_HIP(hipMemcpy(c, s->counters.p, sizeof(c), hipMemcpyDeviceToHost));
         s->stats.node_visits += c[0];
         s->stats.prim_tests += c[1];
@@ -981,6 +1046,9 @@ int rt_scene_stats(const RtScene *cs, RtStats *out) {
                          (double)c[6] / (double)(c[2] + c[4]), c[7]),
             std::fprintf(stderr, "[rtcore] refills take %.1f %% of the waves' time, %.0f clocks each\n",
                          100.0 * (double)c[8] / (double)(c[9] ? c[9] : 1), (double)c[8] / (double)(c[7] ? c[7] : 1));
+        if (std::getenv("RTCORE_DEBUG_STEPS") && c[10] + c[12])
+            std::fprintf(stderr, "[rtcore] pool: pop steps %llu with %.1f lanes, refill steps %llu with %.1f lanes\n", c[10],
+                         c[10] ? (double)c[11] / (double)c[10] : 0.0, c[12], c[12] ? (double)c[13] / (double)c[12] : 0.0);
         RT_HIP(hipMemset(s->counters.p, 0, 128));
     }
     *out = s->stats;

@@ -292,7 +292,7 @@ struct Collapser {
         return c;
     }
     uint32_t leaf_word(uint32_t first, uint32_t count) {
-        if (first > RT_LEAF_FIRST_MASK || count == 0 || count > RT_LEAF_MAX_PRIMS + 1) overflow = true;
+        if (first > RT_LEAF_FIRST_MASK || count == 0 || count > 2) overflow = true;  // the kernels fetch two records per leaf
         return RT_CHILD_LEAF | ((count - 1) << 28) | first;
     }
 
@@ -609,7 +609,7 @@ struct SahCollapser {
     SahCollapser(const std::vector<SahNode> &n, const std::vector<LeafSlot> &s, std::vector<float> &o) : sn(n), slots(s), out(o) {}
     bool is_leaf(int32_t n) const { return sn[n].left < 0; }
     uint32_t leaf_word(const LeafSlot &s) {
-        if (s.first > RT_LEAF_FIRST_MASK || s.count == 0 || s.count > RT_LEAF_MAX_PRIMS + 1) overflow = true;
+        if (s.first > RT_LEAF_FIRST_MASK || s.count == 0 || s.count > 2) overflow = true;  // the kernels fetch two records per leaf
         return RT_CHILD_LEAF | ((s.count - 1) << 28) | s.first;
     }
     uint32_t make(int32_t root, uint32_t depth) {
