@@ -230,6 +230,8 @@ const char *rt_version(void);
  * as src/io.rs:200 takes it from the arguments).
  */
 int rt_scene_create(const RtSceneDesc *desc, RtScene **out);
+/* The same build once, uploaded to every device of `devices` (a device may be named more than once); out[n]. */
+int rt_scene_create_replicas(const RtSceneDesc *desc, const int *devices, int n, RtScene **out);
 /* Host-only dry run of rt_scene_create: validates the description, builds and collapses the
  * tree, fills `info` (device_bytes = what the scene would hold) and frees everything.  Needs no device. */
 int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info);
@@ -283,6 +285,46 @@ int rt_closest_hit_batch_counted_device(RtScene *scene, const float *d_org_dir, 
 int rt_closest_hit_batch_noalloc_device(RtScene *scene, const float *d_org_dir, float t_min, float t_max,
                                         size_t n, int32_t *d_prim_id, float *d_t, float *d_normal,
                                         float *d_point, void *stream);
+
+/*
+ * Several GPUs.  The reference renders its passes one after another on one host and adds them up
+ * (src/main.rs:256-288, src/render.rs:214); passes are independent, so they are dealt round-robin to replicas of the
+ * scene, one per GPU, each adding into an accumulator that stays on its GPU, and the accumulators are summed ONCE
+ * when the passes are done.
+ *
+ * One process, n GPUs (the shape of the reference's host):
+ *   rt_multi_gpu_init        one host build, one replica per entry of `devices` (an entry may repeat: several
+ *                            replicas on one GPU rehearse the path on a one-GPU machine)
+ *   rt_render_passes_multi   passes first_pass .. first_pass + n_passes - 1 (params->pass_index is ignored), replica g
+ *                            takes first_pass + g, + g + n, ...; one host thread per replica; then rt_reduce, one
+ *                            download, and accum_rgb[i] += sum[i].  The frame equals the one-GPU frame of the same
+ *                            passes up to the order of the float additions across replicas.
+ *   rt_reduce                d_bufs[0] += d_bufs[1] + ... (d_bufs[g] on devices[g], n_floats each; work on them must
+ *                            have completed).  how: 0 = RCCL reduce over xGMI when the RCCL library can be loaded and
+ *                            the devices are distinct, else peer copies + an add kernel on devices[0]; 1 = RCCL or
+ *                            fail; 2 = peer copies.  Synchronous.  rt_multi_gpu_last_reduce tells which ran (1 / 2).
+ * One process per GPU (launched by torchrun, MPI, ...):
+ *   rt_comm_unique_id on one rank, the 128 bytes handed to every rank by the caller's own means,
+ *   rt_comm_init_rank on every rank with its GPU current, rt_comm_reduce (in place, sum, result on `root`,
+ *   enqueued on `stream`, no host synchronisation), rt_comm_destroy.
+ * RCCL is loaded at run time (librccl.so.1); without it everything but how = 1 and rt_comm_* still works.
+ */
+typedef struct RtMulti RtMulti;
+typedef struct RtComm RtComm;
+int rt_multi_gpu_init(const RtSceneDesc *desc, const int *devices, int n_devices, RtMulti **out);
+int rt_multi_gpu_destroy(RtMulti *multi);
+int rt_multi_gpu_count(const RtMulti *multi);
+RtScene *rt_multi_gpu_scene(RtMulti *multi, int i);
+int rt_render_passes_multi(RtMulti *multi, const RtRenderParams *params, uint32_t first_pass, uint32_t n_passes,
+                           float *accum_rgb);
+int rt_reduce(RtMulti *multi, float *const *d_bufs, size_t n_floats, int how);
+int rt_multi_gpu_last_reduce(const RtMulti *multi);
+int rt_multi_gpu_stats(RtMulti *multi, RtStats *total); /* sum over the replicas; resets their counters */
+int rt_comm_available(void);
+int rt_comm_unique_id(unsigned char id[128]);
+int rt_comm_init_rank(const unsigned char id[128], int rank, int world, RtComm **out);
+int rt_comm_reduce(RtComm *comm, float *d_buf, size_t n_floats, int root, void *stream);
+int rt_comm_destroy(RtComm *comm);
 
 /* When nonzero, render passes time their stages with HIP events into RtStats (adds syncs). */
 int rt_set_stage_timing(RtScene *scene, int enabled);

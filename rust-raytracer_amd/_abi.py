@@ -165,6 +165,20 @@ SYMBOLS = {
         C.c_int,
         [_VP, _VP, C.c_float, C.c_float, C.c_size_t, _VP, _VP, _VP, _VP, _VP],
     ),
+    "rt_scene_create_replicas": (C.c_int, [C.POINTER(RtSceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(_VP)]),
+    "rt_multi_gpu_init": (C.c_int, [C.POINTER(RtSceneDesc), C.POINTER(C.c_int), C.c_int, C.POINTER(_VP)]),
+    "rt_multi_gpu_destroy": (C.c_int, [_VP]),
+    "rt_multi_gpu_count": (C.c_int, [_VP]),
+    "rt_multi_gpu_scene": (_VP, [_VP, C.c_int]),
+    "rt_render_passes_multi": (C.c_int, [_VP, C.POINTER(RtRenderParams), C.c_uint32, C.c_uint32, _VP]),
+    "rt_reduce": (C.c_int, [_VP, C.POINTER(_VP), C.c_size_t, C.c_int]),
+    "rt_multi_gpu_last_reduce": (C.c_int, [_VP]),
+    "rt_multi_gpu_stats": (C.c_int, [_VP, C.POINTER(RtStats)]),
+    "rt_comm_available": (C.c_int, []),
+    "rt_comm_unique_id": (C.c_int, [_VP]),
+    "rt_comm_init_rank": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "rt_comm_reduce": (C.c_int, [_VP, _VP, C.c_size_t, C.c_int, _VP]),
+    "rt_comm_destroy": (C.c_int, [_VP]),
     "rt_set_stage_timing": (C.c_int, [_VP, C.c_int]),
     "rt_set_counting": (C.c_int, [_VP, C.c_int]),
     "rt_tonemap_device": (C.c_int, [_VP, C.c_size_t, C.c_float, C.c_float, _VP, _VP]),

@@ -909,24 +909,22 @@ int rt_init(int device) {
     return scratch_base(cur, &base);  // the no-allocation entry point's work memory on this device
 }
 
-int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
-    if (!desc || !out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
-    *out = nullptr;
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
-        return fail(RT_ERR_DEVICE, "no HIP device is visible; the core has no CPU path");
+// Uploads a built scene to the CURRENT device.  `h` keeps its arrays (several replicas may be made from one build).
+static int upload_scene(const rtcore::HostScene &h, RtScene **out) {
     std::unique_ptr<RtScene> s(new RtScene());
-    std::string err;
-    int rc = rtcore::build_host_scene(desc, s->host, err);
-    if (rc) return fail(rc, err);
+    // metadata only: the device copies are what the kernels read
+    s->host.env_w = h.env_w, s->host.env_h = h.env_h;
+    for (int k = 0; k < 3; k++) s->host.root_lo[k] = h.root_lo[k], s->host.root_hi[k] = h.root_hi[k];
+    s->host.n_prims = h.n_prims, s->host.n_triangles = h.n_triangles, s->host.n_nodes = h.n_nodes;
+    s->host.n_binary_nodes = h.n_binary_nodes, s->host.wide_depth = h.wide_depth, s->host.max_stack = h.max_stack;
+    s->host.camera = h.camera;
     RT_HIP(hipGetDevice(&s->device));
     hipDeviceProp_t prop;
     RT_HIP(hipGetDeviceProperties(&prop, s->device));
     s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     s->extend_blocks = resident_extend_blocks(s->n_cus);
     if (const char *e = std::getenv("RTCORE_EXTEND")) s->pooled = std::string(e) == "pool";
-
-    rtcore::HostScene &h = s->host;
+    int rc;
     auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
         if (bytes == 0) return RT_OK;
         int r = b.ensure(bytes + 128);  // 128 spare bytes, see ensure_work
@@ -952,12 +950,49 @@ int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
     v.n_prims = (uint32_t)h.n_prims;
     for (int k = 0; k < 3; k++) v.root_lo[k] = h.root_lo[k], v.root_hi[k] = h.root_hi[k];
     v.max_stack = h.max_stack;
-    // the device copies are what the kernels read; drop the host arrays
-    std::vector<float>().swap(h.nodes);
-    std::vector<uint32_t>().swap(h.prims);
-    std::vector<float>().swap(h.shade_records);
-    std::vector<float>().swap(h.env);
     *out = s.release();
+    return RT_OK;
+}
+
+int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
+    int dev = 0;
+    if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return fail(RT_ERR_DEVICE, "no HIP device is visible; the core has no CPU path");
+    RT_HIP(hipGetDevice(&dev));
+    return rt_scene_create_replicas(desc, &dev, 1, out);
+}
+
+// One host build, one upload per entry of `devices` (a device may be named more than once).
+int rt_scene_create_replicas(const RtSceneDesc *desc, const int *devices, int n, RtScene **out) {
+    if (!desc || !out || !devices || n < 1) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
+        return fail(RT_ERR_DEVICE, "no HIP device is visible; the core has no CPU path");
+    for (int i = 0; i < n; i++)
+        if (devices[i] < 0 || devices[i] >= n_dev) return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
+    int before = 0;
+    RT_HIP(hipGetDevice(&before));
+    rtcore::HostScene h;
+    std::string err;
+    int rc = rtcore::build_host_scene(desc, h, err);
+    if (rc) return fail(rc, err);
+    for (int i = 0; i < n && rc == RT_OK; i++) {
+        if (hipSetDevice(devices[i]) != hipSuccess) rc = fail(RT_ERR_DEVICE, "hipSetDevice failed");
+        if (rc == RT_OK) rc = upload_scene(h, &out[i]);
+    }
+    (void)hipSetDevice(before);
+    if (rc != RT_OK) {
+        const std::string msg = g_error;
+        for (int i = 0; i < n; i++) {
+            if (out[i]) rt_scene_destroy(out[i]);
+            out[i] = nullptr;
+        }
+        return fail(rc, msg);
+    }
     return RT_OK;
 }
 

@@ -1,13 +1,17 @@
 // image_io.hpp -- host-side image helpers of the headless driver:
 //   * Radiance .hdr (RGBE) reader standing in for the `radiant` crate (src/io.rs:108);
-//   * PNG writer (8-bit RGB) standing in for io::save_colors_as_image (src/io.rs:310-336);
+//   * PNG writer (8-bit RGB, zlib level 9, adaptive row filters) standing in for io::save_colors_as_image
+//     (src/io.rs:310-336);
 // None of this is on the GPU path.
 #ifndef RT_HOST_IMAGE_IO_HPP
 #define RT_HOST_IMAGE_IO_HPP
 
+#include <zlib.h>
+
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <stdexcept>
@@ -85,20 +89,59 @@ inline HdrImage load_hdr(const std::string &path) {
     return img;
 }
 
-// Writes a flat RGBE file (used to ship a procedural environment as a fixture).
-inline void save_hdr(const std::string &path, uint32_t w, uint32_t h, const float *rgb) {
+// float RGB -> RGBE (Ward's float2rgbe: mantissas truncated, shared exponent of the largest component)
+inline void float_to_rgbe(const float *c, uint8_t px[4]) {
+    float m = std::fmax(c[0], std::fmax(c[1], c[2]));
+    px[0] = px[1] = px[2] = px[3] = 0;
+    if (m > 1e-32f) {
+        int e;
+        float f = std::frexp(m, &e) * 256.0f / m;
+        px[0] = (uint8_t)(c[0] * f), px[1] = (uint8_t)(c[1] * f), px[2] = (uint8_t)(c[2] * f), px[3] = (uint8_t)(e + 128);
+    }
+}
+
+// Writes a Radiance file, -Y H +X W: flat RGBE pixels, or (rle) new-style run-length encoded scanlines -- each
+// scanline "2 2 hi(W) lo(W)" followed by its four channels one after another, as runs (128 + n, value) of 4..127
+// equal bytes and literal stretches (n, bytes...) of at most 128.  Used to ship procedural environments as files.
+inline void save_hdr(const std::string &path, uint32_t w, uint32_t h, const float *rgb, bool rle = false) {
     std::ofstream out(path, std::ios::binary);
+    if (!out) throw std::runtime_error("cannot write " + path);
     out << "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y " << h << " +X " << w << "\n";
-    for (size_t i = 0; i < (size_t)w * h; i++) {
-        float r = rgb[3 * i], g = rgb[3 * i + 1], b = rgb[3 * i + 2];
-        float m = std::fmax(r, std::fmax(g, b));
-        uint8_t px[4] = {0, 0, 0, 0};
-        if (m > 1e-32f) {
-            int e;
-            float f = std::frexp(m, &e) * 256.0f / m;
-            px[0] = (uint8_t)(r * f), px[1] = (uint8_t)(g * f), px[2] = (uint8_t)(b * f), px[3] = (uint8_t)(e + 128);
+    rle = rle && w >= 8 && w < 32768;
+    std::vector<uint8_t> scan((size_t)w * 4), enc;
+    for (uint32_t y = 0; y < h; y++) {
+        for (uint32_t x = 0; x < w; x++) float_to_rgbe(rgb + ((size_t)y * w + x) * 3, &scan[(size_t)x * 4]);
+        if (!rle) {
+            out.write((const char *)scan.data(), (std::streamsize)scan.size());
+            continue;
         }
-        out.write((const char *)px, 4);
+        enc.clear();
+        enc.push_back(2), enc.push_back(2), enc.push_back((uint8_t)(w >> 8)), enc.push_back((uint8_t)(w & 0xFF));
+        for (int c = 0; c < 4; c++) {
+            uint32_t x = 0;
+            while (x < w) {
+                // length of the run of equal bytes starting at x
+                uint32_t run = 1;
+                while (x + run < w && run < 127 && scan[(size_t)(x + run) * 4 + c] == scan[(size_t)x * 4 + c]) run++;
+                if (run >= 4) {
+                    enc.push_back((uint8_t)(128 + run)), enc.push_back(scan[(size_t)x * 4 + c]);
+                    x += run;
+                    continue;
+                }
+                // a literal stretch: up to the next run of at least 4, at most 128 bytes
+                uint32_t n = 0;
+                while (x + n < w && n < 128) {
+                    uint32_t r = 1;
+                    while (x + n + r < w && r < 4 && scan[(size_t)(x + n + r) * 4 + c] == scan[(size_t)(x + n) * 4 + c]) r++;
+                    if (r >= 4) break;
+                    n++;
+                }
+                enc.push_back((uint8_t)n);
+                for (uint32_t k = 0; k < n; k++) enc.push_back(scan[(size_t)(x + k) * 4 + c]);
+                x += n;
+            }
+        }
+        out.write((const char *)enc.data(), (std::streamsize)enc.size());
     }
 }
 
@@ -132,8 +175,11 @@ inline void chunk(std::ofstream &out, const char *type, const std::vector<uint8_
 }
 }  // namespace detail
 
-// 8-bit RGB PNG from packed 0xFFRRGGBB pixels (alpha dropped as int_to_rgb does, src/io.rs:301-307).
-// The zlib stream uses stored blocks: valid everywhere, no compression library needed.
+// 8-bit RGB PNG from packed 0xFFRRGGBB pixels (alpha dropped as int_to_rgb does, src/io.rs:301-307), written as the
+// reference asks its encoder to (src/io.rs:319-325): Compression::Best = zlib's level 9, and an adaptive filter: for
+// every row the one of the five PNG filters whose output has the smallest sum of absolute values (bytes read as
+// signed), the usual minimum-sum-of-absolute-differences heuristic.  The pixels a decoder gets back are what matters;
+// the compressed bytes themselves need not equal another encoder's.
 inline void save_png(const std::string &path, const uint32_t *argb, uint32_t w, uint32_t h) {
     std::ofstream out(path, std::ios::binary);
     if (!out) throw std::runtime_error("cannot write " + path);
@@ -144,34 +190,44 @@ inline void save_png(const std::string &path, const uint32_t *argb, uint32_t w, 
     detail::put32(ihdr, h);
     ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});
     detail::chunk(out, "IHDR", ihdr);
+    const size_t stride = 3 * (size_t)w;
     std::vector<uint8_t> raw;
-    raw.reserve((size_t)h * (1 + 3 * (size_t)w));
+    raw.reserve((size_t)h * (1 + stride));
+    std::vector<uint8_t> cur(stride), prev(stride, 0), cand[5];
+    for (auto &c : cand) c.resize(stride);
     for (uint32_t y = 0; y < h; y++) {
-        raw.push_back(0);
         for (uint32_t x = 0; x < w; x++) {
             uint32_t c = argb[(size_t)y * w + x];
-            raw.push_back((c >> 16) & 0xFF), raw.push_back((c >> 8) & 0xFF), raw.push_back(c & 0xFF);
+            cur[3 * (size_t)x] = (c >> 16) & 0xFF, cur[3 * (size_t)x + 1] = (c >> 8) & 0xFF, cur[3 * (size_t)x + 2] = c & 0xFF;
         }
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= 3 ? cur[i - 3] : 0, b = prev[i], c = i >= 3 ? prev[i - 3] : 0;
+            const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+            const int paeth = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            cand[0][i] = cur[i];
+            cand[1][i] = (uint8_t)(cur[i] - a);
+            cand[2][i] = (uint8_t)(cur[i] - b);
+            cand[3][i] = (uint8_t)(cur[i] - ((a + b) >> 1));
+            cand[4][i] = (uint8_t)(cur[i] - paeth);
+        }
+        int best = 0;
+        uint64_t best_sum = ~0ull;
+        for (int f = 0; f < 5; f++) {
+            uint64_t sum = 0;
+            for (size_t i = 0; i < stride; i++) sum += (uint64_t)std::abs((int)(int8_t)cand[f][i]);
+            if (sum < best_sum) best_sum = sum, best = f;
+        }
+        raw.push_back((uint8_t)best);
+        raw.insert(raw.end(), cand[best].begin(), cand[best].end());
+        prev = cur;
     }
-    std::vector<uint8_t> z = {0x78, 0x01};
-    uint32_t a = 1, b = 0;
-    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
-        size_t n = raw.size() - off < 65535 ? raw.size() - off : 65535;
-        bool last = off + n >= raw.size();
-        z.push_back(last ? 1 : 0);
-        z.push_back(n & 0xFF), z.push_back(n >> 8), z.push_back(~n & 0xFF), z.push_back((~n >> 8) & 0xFF);
-        z.insert(z.end(), raw.begin() + (long)off, raw.begin() + (long)(off + n));
-        if (last) break;
-    }
-    for (uint8_t v : raw) {
-        a = (a + v) % 65521;
-        b = (b + a) % 65521;
-    }
-    detail::put32(z, (b << 16) | a);
+    uLongf bound = compressBound((uLong)raw.size());
+    std::vector<uint8_t> z(bound);
+    if (compress2(z.data(), &bound, raw.data(), (uLong)raw.size(), 9) != Z_OK) throw std::runtime_error("zlib: compress2 failed");
+    z.resize(bound);
     detail::chunk(out, "IDAT", z);
     detail::chunk(out, "IEND", {});
 }
-
 
 }  // namespace imageio
 #endif

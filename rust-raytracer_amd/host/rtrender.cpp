@@ -8,7 +8,7 @@
 // no light clamp).  There is no window: the preview loop and the key handling are gone, the image is
 // written when the passes are done (the reference writes output/<unix millis>.png on Enter).
 // --gpus N renders passes round-robin on N devices from one process (one host thread and one scene
-// replica per device) and sums the accumulators on the host.
+// replica per device, accumulators resident on the devices) and sums the accumulators once, on the devices.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -30,6 +30,8 @@ struct Args {
     bool filter = false, preview = false, validate = false;
     uint32_t seed = 0;
     int gpus = 1;
+    bool same_device = false;  // --gpus replicas all on device 0 (rehearsal on a one-GPU machine)
+    uint32_t sync_every = 0;
     std::string out;
     int mode = RT_MODE_IMAGE;
 };
@@ -49,6 +51,8 @@ static void usage() {
         "  -f, --filter                     apply bilateral filter after render to reduce noise\n"
         "      --seed <SEED>                seed of the counter-based generators [default: 0]\n"
         "      --gpus <N>                   devices to spread the passes over [default: 1]\n"
+        "      --same-device                put all --gpus replicas on device 0 (rehearsal on one GPU)\n"
+        "      --sync-every <N>             with several devices: sum and report every N rounds of passes [default: once]\n"
         "      --out <FILE>                 PNG to write [default: output/<unix millis>.png]\n"
         "      --mode <image|colors|normals>\n"
         "      --preview                    one preview frame (1 sample, no bounce) instead of the passes\n"
@@ -78,6 +82,8 @@ static bool parse_args(int argc, char **argv, Args &a) {
         else if (k == "-f" || k == "--filter") a.filter = true;
         else if (k == "--seed") a.seed = (uint32_t)std::strtoul(val(), nullptr, 10);
         else if (k == "--gpus") a.gpus = std::atoi(val());
+        else if (k == "--same-device") a.same_device = true;
+        else if (k == "--sync-every") a.sync_every = (uint32_t)std::strtoul(val(), nullptr, 10);
         else if (k == "--out") a.out = val();
         else if (k == "--preview") a.preview = true;
         else if (k == "--validate") a.validate = true;
@@ -130,19 +136,21 @@ int main(int argc, char **argv) {
                     desc.camera.lookat[2], desc.camera.fov_degrees, desc.camera.focus_dist, desc.camera.aperture);
         return 0;
     }
-    std::vector<RtScene *> scenes((size_t)args.gpus, nullptr);
-    for (int g = 0; g < args.gpus; g++) {
-        if (rt_init(g) != RT_OK || rt_scene_create(&desc, &scenes[(size_t)g]) != RT_OK) {
-            std::fprintf(stderr, "error: %s\n", rt_last_error());
-            return 1;
-        }
+    // One replica of the scene per device (one host build), passes dealt round-robin, accumulators resident on
+    // their devices, ONE sum at the end (RCCL over xGMI, or peer copies): rt_multi_gpu_* of the library.
+    std::vector<int> devices((size_t)args.gpus);
+    for (int g = 0; g < args.gpus; g++) devices[(size_t)g] = args.same_device ? 0 : g;
+    RtMulti *multi = nullptr;
+    if (rt_init(devices[0]) != RT_OK || rt_multi_gpu_init(&desc, devices.data(), args.gpus, &multi) != RT_OK) {
+        std::fprintf(stderr, "error: %s\n", rt_last_error());
+        return 1;
     }
     const size_t n_px = (size_t)args.width * args.height;
     std::vector<float> buffer(n_px * 3, 0.0f);
     uint32_t passes_done = 0;
     if (args.preview) {
-        RtRenderParams p{args.width, args.height, 1, args.bounces, args.light_clamp, args.mode, 0, args.seed, 0};
-        if (rt_init(0) != RT_OK || rt_preview(scenes[0], &p, buffer.data()) != RT_OK) {
+        RtRenderParams p{args.width, args.height, 1, args.bounces, args.light_clamp, args.mode, 0, args.seed, 0, 0, 0};
+        if (rt_preview(rt_multi_gpu_scene(multi, 0), &p, buffer.data()) != RT_OK) {
             std::fprintf(stderr, "error: %s\n", rt_last_error());
             return 1;
         }
@@ -150,41 +158,31 @@ int main(int argc, char **argv) {
     } else {
         std::printf("Rendering with %u passes with %u rays per pixel\n", args.passes, args.samples);
         double total = 0.0;
-        std::vector<std::vector<float>> partial((size_t)args.gpus);
-        for (auto &b : partial) b.assign(n_px * 3, 0.0f);
-        for (uint32_t pass = 0; pass < args.passes; pass += (uint32_t)args.gpus) {
+        RtRenderParams p{args.width, args.height, args.samples, args.bounces, args.light_clamp, args.mode, 0, args.seed, 0, 0, 0};
+        // With one device the reference's loop is kept (a print per pass, src/main.rs:259-278); with several the
+        // passes run concurrently and are summed once, so there is one print per round of `gpus` passes at most:
+        // --sync-every N sums and reports every N rounds (0 = once, at the end).
+        const uint32_t per_round = (uint32_t)args.gpus * (args.gpus > 1 ? (args.sync_every ? args.sync_every : args.passes) : 1u);
+        for (uint32_t pass = 0; pass < args.passes; pass += per_round) {
             std::printf("rendering...\n");
+            const uint32_t count = std::min<uint32_t>(per_round, args.passes - pass);
             auto t0 = std::chrono::steady_clock::now();
-            std::vector<std::thread> workers;
-            std::vector<int> rc((size_t)args.gpus, RT_OK);
-            uint32_t in_flight = std::min<uint32_t>((uint32_t)args.gpus, args.passes - pass);
-            for (uint32_t g = 0; g < in_flight; g++) {
-                workers.emplace_back([&, g]() {
-                    RtRenderParams p{args.width, args.height, args.samples, args.bounces, args.light_clamp, args.mode,
-                                     pass + g, args.seed, 0};
-                    rc[g] = rt_init((int)g);
-                    if (rc[g] == RT_OK) rc[g] = rt_render_pass(scenes[g], &p, partial[g].data());
-                    if (rc[g] != RT_OK) std::fprintf(stderr, "error: %s\n", rt_last_error());
-                });
+            if (rt_render_passes_multi(multi, &p, pass, count, buffer.data()) != RT_OK) {
+                std::fprintf(stderr, "error: %s\n", rt_last_error());
+                return 1;
             }
-            for (auto &w : workers) w.join();
-            for (int r : rc)
-                if (r != RT_OK) return 1;
             double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             total += dt;
-            passes_done += in_flight;
-            std::printf("Frame took %g seconds.\n", dt / in_flight);
+            passes_done += count;
+            std::printf("Frame took %g seconds.\n", dt / count);
             std::printf("finished pass %u\n", passes_done);
         }
-        for (auto &b : partial)
-            for (size_t i = 0; i < buffer.size(); i++) buffer[i] += b[i];
         std::printf("Average frame time %g seconds.\n", total / (passes_done ? passes_done : 1));
-        uint64_t rays = 0;
-        for (int g = 0; g < args.gpus; g++) {
-            RtStats st;
-            if (rt_init(g) == RT_OK && rt_scene_stats(scenes[(size_t)g], &st) == RT_OK) rays += st.rays;
-        }
-        std::printf("%.1f Mrays/s (%llu rays)\n", rays / total / 1e6, (unsigned long long)rays);
+        RtStats st;
+        if (rt_multi_gpu_stats(multi, &st) == RT_OK)
+            std::printf("%.1f Mrays/s (%llu rays) on %d device(s), accumulators summed by %s\n", st.rays / total / 1e6,
+                        (unsigned long long)st.rays, args.gpus,
+                        rt_multi_gpu_last_reduce(multi) == 1 ? "RCCL" : (rt_multi_gpu_last_reduce(multi) == 2 ? "peer copies" : "nothing (one device)"));
         // Normalize samples (src/main.rs:288)
         for (float &v : buffer) v = v / (float)passes_done;
     }
@@ -216,6 +214,6 @@ int main(int argc, char **argv) {
     } catch (const std::exception &e) {
         std::fprintf(stderr, "warning: %s\n", e.what());  // the reference swallows the error (.ok(), src/main.rs:158)
     }
-    for (RtScene *s : scenes) rt_scene_destroy(s);
+    rt_multi_gpu_destroy(multi);
     return 0;
 }

@@ -50,3 +50,44 @@ def render_split_frame(render_range, accum, n_pixels, rank=0, world=1, reduce_to
             import torch.distributed as dist
         dist.reduce(accum, dst=reduce_to)
     return first, count
+
+
+# ---- the library's own RCCL reduce, for one process per GPU ------------------------------------------------
+_comm = None
+
+
+def native_comm_init(rank, world, dist=None):
+    """Builds the library's communicator (rt_comm_init_rank): rank 0 draws the id, the caller's process group (any
+    backend) hands its 128 bytes round.  The current device must be this rank's GPU."""
+    import ctypes as C
+
+    import torch
+
+    from . import _abi
+
+    global _comm
+    if _comm is not None:
+        return _comm
+    if dist is None:
+        import torch.distributed as dist
+    lib = _abi.load()
+    ident = (C.c_ubyte * 128)()
+    if rank == 0:
+        _abi.check(lib.rt_comm_unique_id(ident))
+    t = torch.tensor(list(ident), dtype=torch.uint8)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=0)
+    ident = (C.c_ubyte * 128)(*t.cpu().tolist())
+    h = C.c_void_p()
+    _abi.check(lib.rt_comm_init_rank(ident, rank, world, C.byref(h)))
+    _comm = h
+    return h
+
+
+def native_reduce(accum, rank, world, stream=0, root=0):
+    """Sum of the ranks' device tensors `accum` into rank `root`'s, in place, enqueued on `stream`."""
+    from . import _abi
+
+    assert _comm is not None, "native_comm_init first"
+    _abi.check(_abi.load().rt_comm_reduce(_comm, accum.data_ptr(), accum.numel(), root, stream))

@@ -121,6 +121,50 @@ class Scene:
         _abi.check(self._lib.rt_preview_device(self._h, C.byref(params), d_out, stream))
 
 
+class MultiScene:
+    """Replicas of one scene on several GPUs of this process (rt_multi_gpu_*): passes are dealt round-robin, the
+    device-resident accumulators are summed once (RCCL over xGMI, or peer copies) and added to the caller's frame."""
+
+    def __init__(self, description, devices):
+        self._lib = _abi.load()
+        self._owner = description
+        desc = description.to_desc()
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        _abi.check(self._lib.rt_multi_gpu_init(C.byref(desc), devs, len(devices), C.byref(h)))
+        self._h = h
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rt_multi_gpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_passes(self, accum, params, first_pass, n_passes):
+        """accum: float32 host array [height*width*3]; the sum of the passes is added to it."""
+        assert accum.dtype == np.float32 and accum.flags["C_CONTIGUOUS"] and accum.size == params.width * params.height * 3
+        _abi.check(self._lib.rt_render_passes_multi(self._h, C.byref(params), first_pass, n_passes, _ptr(accum)))
+
+    def reduce(self, device_pointers, n_floats, how=0):
+        """device_pointers[g] (ints) on devices[g]; the sum lands in device_pointers[0].  how: 0 auto, 1 RCCL, 2 peer copies."""
+        arr = (C.c_void_p * len(device_pointers))(*device_pointers)
+        _abi.check(self._lib.rt_reduce(self._h, arr, n_floats, how))
+
+    def last_reduce(self):
+        return {0: "none", 1: "rccl", 2: "peer"}[self._lib.rt_multi_gpu_last_reduce(self._h)]
+
+    def stats(self):
+        s = _abi.RtStats()
+        _abi.check(self._lib.rt_multi_gpu_stats(self._h, C.byref(s)))
+        return s
+
+
 class Renderer:
     """Renderer { width, height, camera, world, sample_rate, max_bounce, hdr, light_clamp } (src/render.rs:151-160).
 

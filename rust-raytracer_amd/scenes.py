@@ -222,5 +222,24 @@ def teaset(fixture=None, env_size=(2048, 1024)):
     add("cup", "glass", (1.5, 0.6, -0.5), (0.05, 0.05, 0.05), (0.0, 0.0, 0.0), False)
     add("spoon", "stainless steel", (-0.9, 0.085, 0.3), (1.5, 1.5, 1.5), (0.025, -0.8, 0.0), True)
     if env_size:
-        s.set_environment(sky_map(env_size[0], env_size[1]))
+        s.set_environment(sky_environment(env_size[0], env_size[1]))
     return s
+
+
+def sky_environment(width, height):
+    """The procedural sky as the renderer gets it from a scene file's `hdr:` entry: written as a Radiance .hdr and read
+    back through the C++ host's RGBE reader (src/io.rs:106-111 reads the file with the radiant crate), i.e. with the
+    values a real .hdr can hold.  512 x 256 comes from the committed fixture tests/golden/sky_512x256_flat.hdr; other
+    sizes are generated, written to a temporary file and read back the same way."""
+    import os
+    import tempfile
+
+    from . import hostio
+
+    golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sky_512x256_flat.hdr")
+    if (width, height) == (512, 256) and os.path.exists(golden):
+        return hostio.load_hdr(golden)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "sky.hdr")
+        hostio.save_hdr(path, sky_map(width, height), rle=True)
+        return hostio.load_hdr(path)

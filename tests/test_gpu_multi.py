@@ -1,0 +1,95 @@
+"""The library's own multi-GPU path on one GPU: scene replicas (here several on device 0), passes dealt round-robin,
+device-resident accumulators, one sum at the end.  The peer-copy sum is exercised device -> same device; the RCCL
+binding through a one-rank communicator."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTRENDER = os.path.join(ROOT, "rust-raytracer_amd", "rtrender")
+
+
+def _single(pkg, scene, W, H, spp, passes, seed):
+    acc = np.zeros(W * H * 3, np.float32)
+    for i in passes:
+        scene.render_pass(acc, pkg.Scene.params(W, H, spp, 8, pass_index=i, seed=seed))
+    return acc
+
+
+def test_one_replica_is_the_single_gpu_frame(pkg):
+    d = pkg.scenes.cornell()
+    W, H, spp = 96, 64, 4
+    multi = pkg.MultiScene(d, [0])
+    acc = np.full(W * H * 3, 0.5, np.float32)  # the sum is ADDED to what the caller holds
+    multi.render_passes(acc, pkg.Scene.params(W, H, spp, 8, seed=3), 2, 3)
+    want = _single(pkg, pkg.Scene(d), W, H, spp, [2, 3, 4], 3)
+    assert np.array_equal(acc.view(np.uint32), (np.float32(0.5) + want).view(np.uint32))
+    assert multi.last_reduce() == "none"
+    st = multi.stats()
+    assert st.paths == 3 * W * H * spp
+
+
+def test_three_replicas_on_one_device_sum_by_peer_copies(pkg):
+    d = pkg.scenes.rtiow(seed=2)
+    W, H, spp, n_passes = 80, 48, 3, 7
+    multi = pkg.MultiScene(d, [0, 0, 0])
+    acc = np.zeros(W * H * 3, np.float32)
+    multi.render_passes(acc, pkg.Scene.params(W, H, spp, 8, seed=11), 0, n_passes)
+    assert multi.last_reduce() == "peer"  # replicas share a device: no RCCL communicator possible
+    scene = pkg.Scene(d)
+    parts = [_single(pkg, scene, W, H, spp, range(g, n_passes, 3), 11) for g in range(3)]
+    want = (parts[0] + parts[1]) + parts[2]  # the order in which the sum adds the replicas
+    assert np.array_equal(acc.view(np.uint32), want.view(np.uint32))
+    sequential = _single(pkg, scene, W, H, spp, range(n_passes), 11)
+    assert np.allclose(acc, sequential, rtol=1e-5, atol=1e-6)  # same passes, other order of additions
+    assert multi.stats().paths == n_passes * W * H * spp
+
+
+def test_reduce_entry_point_and_one_rank_communicator(pkg):
+    import torch
+
+    lib = pkg.load()
+    d = pkg.scenes.cornell()
+    multi = pkg.MultiScene(d, [0, 0])
+    n = 1_000_003
+    a = torch.arange(n, dtype=torch.float32, device="cuda")
+    b = torch.full((n,), 0.25, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    multi.reduce([a.data_ptr(), b.data_ptr()], n, how=2)
+    assert torch.equal(a, torch.arange(n, dtype=torch.float32, device="cuda") + 0.25)
+    assert torch.equal(b, torch.full((n,), 0.25, dtype=torch.float32, device="cuda"))
+    with pytest.raises(pkg.RtError):
+        multi.reduce([a.data_ptr(), b.data_ptr()], n, how=1)  # RCCL needs distinct devices
+    # the RCCL binding: a communicator of one rank on this GPU, sum in place
+    assert lib.rt_comm_available() == 1
+    ident = (C.c_ubyte * 128)()
+    pkg._abi.check(lib.rt_comm_unique_id(ident))
+    comm = C.c_void_p()
+    pkg._abi.check(lib.rt_comm_init_rank(ident, 0, 1, C.byref(comm)))
+    before = a.clone()
+    pkg._abi.check(lib.rt_comm_reduce(comm, a.data_ptr(), n, 0, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(a, before)
+    pkg._abi.check(lib.rt_comm_destroy(comm))
+
+
+def test_rtrender_with_two_replicas(tmp_path, pkg):
+    """The C++ host with --gpus 2 (both replicas on device 0): the library's multi path end to end."""
+    d = pkg.scenes.cornell()
+    scene_file = tmp_path / "cornell.ron"
+    scene_file.write_text(pkg.scene.to_ron(d))
+    outs = []
+    for extra in (["--gpus", "1"], ["--gpus", "2", "--same-device"]):
+        out = tmp_path / ("out%d.png" % len(outs))
+        log = subprocess.check_output([RTRENDER, str(scene_file), "--width", "90", "--height", "60", "-s", "8", "-p", "4", "-b", "8",
+                                       "--seed", "5", "--out", str(out)] + extra).decode()
+        assert "Average frame time" in log and "finished pass 4" in log
+        outs.append(out.read_bytes())
+    assert "peer copies" in log
+    # two replicas add the passes in another order: the 8-bit frames may differ in a last bit here and there
+    a, b = np.frombuffer(outs[0], np.uint8), np.frombuffer(outs[1], np.uint8)
+    assert len(a) == len(b) and (a != b).mean() < 0.01

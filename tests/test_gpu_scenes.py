@@ -111,19 +111,11 @@ def test_closest_hit_microbench_checks(pkg, oracle):
 
 
 def _decode_png(path, W, H):
-    """Pixels of a PNG written with stored deflate blocks and filter 0, as 0xFFRRGGBB."""
-    raw = open(path, "rb").read()
-    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
-    pos, idat = 8, b""
-    while pos < len(raw):
-        n = int.from_bytes(raw[pos:pos + 4], "big")
-        typ = raw[pos + 4:pos + 8]
-        if typ == b"IDAT":
-            idat += raw[pos + 8:pos + 8 + n]
-        assert zlib.crc32(raw[pos + 4:pos + 8 + n]) == int.from_bytes(raw[pos + 8 + n:pos + 12 + n], "big")
-        pos += 12 + n
-    px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, 1 + 3 * W)[:, 1:].reshape(H * W, 3).astype(np.uint32)
-    return (255 << 24) | (px[:, 0] << 16) | (px[:, 1] << 8) | px[:, 2]
+    from pngdec import decode_png
+
+    px, _, size, _ = decode_png(path)
+    assert size == (W, H)
+    return px
 
 
 def test_rtrender_end_to_end(tmp_path, pkg, oracle):

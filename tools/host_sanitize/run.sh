@@ -13,10 +13,10 @@ ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 "$OUT/harness"
 # the scene-file / OBJ / RGBE readers on whole, truncated and corrupted files (pass files as arguments;
 # by default the reference's example scenes and one tea-set model when that checkout is present)
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -static-libasan -static-libubsan -fno-omit-frame-pointer \
-    -I"$ROOT/include" -I"$ROOT/tools/host_sanitize" "$ROOT/tools/host_sanitize/loader_harness.cpp" -o "$OUT/loader_harness"
+    -I"$ROOT/include" -I"$ROOT/tools/host_sanitize" "$ROOT/tools/host_sanitize/loader_harness.cpp" -o "$OUT/loader_harness" -lz
 FILES=("$@")
 if [ ${#FILES[@]} -eq 0 ] && [ -d /root/reference/scene ]; then
-    FILES=(/root/reference/scene/example/*.ron /root/reference/scene/models/newell_teaset/teacup.obj)
+    FILES=(/root/reference/scene/example/*.ron /root/reference/scene/models/newell_teaset/teacup.obj "$ROOT"/tests/golden/sky_512x256_rle.hdr)
 fi
 if [ ${#FILES[@]} -gt 0 ]; then
     ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 "$OUT/loader_harness" "$OUT" "${FILES[@]}"
