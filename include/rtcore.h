@@ -193,10 +193,11 @@ typedef struct RtSceneInfo {
     uint32_t wide_depth;
     uint32_t node_bytes;      /* bytes of one wide node */
     uint32_t primitive_bytes; /* bytes of one primitive record */
-    uint32_t reserved;
+    uint32_t builder;         /* RtBuilder that made the tree (RT_BUILD_EXACT or RT_BUILD_DEVICE) */
     uint64_t device_bytes; /* HBM held by the scene */
     float bounds_min[3];
     float bounds_max[3];
+    double build_ms; /* host clock of the build: description in, tree on the device (0 from rt_scene_validate) */
 } RtSceneInfo;
 
 /* Counters of the last render pass / closest-hit batch on a scene. */
@@ -232,6 +233,21 @@ const char *rt_version(void);
 int rt_scene_create(const RtSceneDesc *desc, RtScene **out);
 /* The same build once, uploaded to every device of `devices` (a device may be named more than once); out[n]. */
 int rt_scene_create_replicas(const RtSceneDesc *desc, const int *devices, int n, RtScene **out);
+/*
+ * Which build makes the tree.
+ *   RT_BUILD_EXACT   (the default) restates Bvh::new on the host (src/tracer/bvh.rs:39-117): the reference's tree,
+ *                    hence the reference's winner among hits at exactly the same t (see "Equal distances" above).
+ *   RT_BUILD_DEVICE  builds on the GPU with no host sort: primitive boxes, Morton order, binary radix tree, the same
+ *                    4-wide collapse.  Primitive records are the same bits as the exact build's, so (prim_id, t,
+ *                    normal) are the same for every ray whose closest hit is not an exact tie between two primitives
+ *                    (which of the two is named then follows this tree's order, not the reference's) and that does not
+ *                    graze a leaf's guard box within rounding.  Two orders of magnitude faster on large meshes.
+ *   RT_BUILD_DEFAULT RT_BUILD_DEVICE when the environment has RTCORE_BUILD=gpu, else RT_BUILD_EXACT.
+ * rt_scene_create(desc, out) is rt_scene_create_with(desc, RT_BUILD_DEFAULT, out).
+ */
+typedef enum RtBuilder { RT_BUILD_DEFAULT = 0, RT_BUILD_EXACT = 1, RT_BUILD_DEVICE = 2 } RtBuilder;
+int rt_scene_create_with(const RtSceneDesc *desc, int builder, RtScene **out);
+int rt_scene_create_replicas_with(const RtSceneDesc *desc, int builder, const int *devices, int n, RtScene **out);
 /* Host-only dry run of rt_scene_create: validates the description, builds and collapses the
  * tree, fills `info` (device_bytes = what the scene would hold) and frees everything.  Needs no device. */
 int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info);

@@ -23,6 +23,7 @@ RT_MAT_DIELECTRIC, RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_GLOSSY = 0, 1, 2, 3
 RT_OBJ_SPHERE, RT_OBJ_ABOX, RT_OBJ_CUBE, RT_OBJ_TRIANGLE, RT_OBJ_MESH = 0, 1, 2, 3, 4
 RT_MODE_NORMALS, RT_MODE_COLORS, RT_MODE_IMAGE = 0, 1, 2
 RT_NOALLOC_MAX_RAYS = 262144
+RT_BUILD_DEFAULT, RT_BUILD_EXACT, RT_BUILD_DEVICE = 0, 1, 2
 
 F3 = C.c_float * 3
 F9 = C.c_float * 9
@@ -114,10 +115,11 @@ class RtSceneInfo(C.Structure):
         ("wide_depth", C.c_uint32),
         ("node_bytes", C.c_uint32),
         ("primitive_bytes", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("builder", C.c_uint32),
         ("device_bytes", C.c_uint64),
         ("bounds_min", F3),
         ("bounds_max", F3),
+        ("build_ms", C.c_double),
     ]
 
 
@@ -147,6 +149,11 @@ SYMBOLS = {
     "rt_last_error": (C.c_char_p, []),
     "rt_version": (C.c_char_p, []),
     "rt_scene_create": (C.c_int, [C.POINTER(RtSceneDesc), C.POINTER(_VP)]),
+    "rt_scene_create_with": (C.c_int, [C.POINTER(RtSceneDesc), C.c_int, C.POINTER(_VP)]),
+    "rt_scene_create_replicas_with": (
+        C.c_int,
+        [C.POINTER(RtSceneDesc), C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(_VP)],
+    ),
     "rt_scene_validate": (C.c_int, [C.POINTER(RtSceneDesc), C.POINTER(RtSceneInfo)]),
     "rt_scene_destroy": (C.c_int, [_VP]),
     "rt_scene_info": (C.c_int, [_VP, C.POINTER(RtSceneInfo)]),

@@ -1,0 +1,825 @@
+// gpu_build.hip -- the scene build on the device (opt-in: RT_BUILD_DEVICE / RTCORE_BUILD=gpu).
+//
+// The default build restates Bvh::new (src/tracer/bvh.rs:39-117) on the host, because the reference's tree --
+// and with it the winner among hits at exactly the same distance -- is defined by a sequential merge sort under a
+// comparator that is not a strict weak order.  A parallel build cannot reproduce that permutation.  What it can
+// keep is everything else the traversal's answer depends on: the primitive records are the same bits (same
+// operations as the host build, -ffp-contract=off), every leaf is guarded by a box that contains its primitives,
+// and interior boxes contain their children.  So this builder gives the same (primitive, t) as the exact build for
+// every ray whose closest hit is not an exact tie between two primitives, up to the rays that graze a guard box
+// within rounding (the reference's guard boxes are the EPSILON-padded unions of Aabb::surrounding_box,
+// src/tracer/cube.rs:179-193; here a two-primitive leaf gets the same padded union and a single primitive its own
+// box, as in the reference's one-child nodes, src/tracer/bvh.rs:46-49).
+//
+// Pipeline (one stream, no host work between the stages except reading one counter per tree level):
+//   1. boxes      primitive boxes in declaration order (mesh faces transformed as Mesh::new does,
+//                 src/tracer/mesh.rs:31-73) + scene bounds (block reduce, ordered-integer atomics)
+//   2. morton     63-bit Morton code of each box centre, radix sort of (code, primitive) pairs
+//   3. emit       records, shade records and leaf boxes in sorted order (array index = "visit rank" of this tree)
+//   4. hierarchy  binary radix tree over the sorted codes (Karras 2012), duplicates split by index
+//   5. fit        bottom-up boxes; the same pass fills the table that picks the roots of the 4-wide nodes:
+//                 the cheapest summed half area of wide-node root boxes for handing a subtree to at most j slots
+//                 (the cost model of the host build's collapse)
+//   6. collapse   top-down, one launch per level of the wide tree; wide nodes are numbered level by level, within a
+//                 level in the order of their parents (block-wide prefix sum, one atomic per block)
+#include <hip/hip_runtime.h>
+
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "gpu_build.hpp"
+#include "rt_device.hpp"
+#include "scene_build.hpp"
+
+namespace rtcore {
+namespace {
+
+using rtd::F3;
+using rtd::f3;
+using rtd::Rotor;
+
+constexpr int kBlock = 256;
+constexpr float kEps = 1.1920929e-7f;  // f32::EPSILON
+constexpr uint32_t kLeafBit = 0x80000000u;
+
+struct MeshDev {       // one mesh OBJECT (a mesh array may serve several objects)
+    float rot[4];      // rotor s, xy, xz, yz
+    float scale[3];
+    uint32_t meta;     // primitive meta word of its faces
+    float tr[3];
+    uint32_t n_vertices;
+    uint64_t vtx_off;  // first vertex in the vertex pools
+    uint64_t face_off; // first face in the index pool
+};
+struct SimpleDev {  // a sphere, box, rotated box or lone triangle: record and box made on the host
+    uint32_t rec[12];
+    float nrm[12];
+    float box[8];  // lo.xyz, pad, hi.xyz, pad
+};
+struct Sources {
+    const uint32_t *seg_first;  // [n_seg] first primitive id of each object, ascending
+    const uint32_t *seg_ref;    // [n_seg] bit 31: mesh, low bits: index into meshes / simples
+    uint32_t n_seg;
+    const MeshDev *meshes;
+    const SimpleDev *simples;
+    const float *pos, *nrm;  // vertex pools (xyz triples)
+    const uint32_t *idx;     // index pool (three per face)
+};
+
+__device__ __forceinline__ float fmin_(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
+__device__ __forceinline__ float fmax_(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+
+__device__ __forceinline__ uint32_t find_segment(const Sources &S, uint32_t p) {
+    uint32_t lo = 0, hi = S.n_seg;  // largest s with seg_first[s] <= p
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (S.seg_first[mid] <= p)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// The three transformed corners and normals of face f of a mesh object (src/tracer/mesh.rs:49-73).
+__device__ __forceinline__ void mesh_face(const Sources &S, const MeshDev &m, uint32_t f, F3 v[3], F3 n[3], uint32_t *bad) {
+    const Rotor rot{m.rot[0], m.rot[1], m.rot[2], m.rot[3]};
+    const F3 sc = f3(m.scale[0], m.scale[1], m.scale[2]), tr = f3(m.tr[0], m.tr[1], m.tr[2]);
+    const uint32_t *ix = S.idx + 3 * (m.face_off + f);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        uint32_t vi = ix[k];
+        if (vi >= m.n_vertices) {
+            *bad = 1;
+            vi = 0;
+        }
+        const float *P = S.pos + 3 * (m.vtx_off + vi), *N = S.nrm + 3 * (m.vtx_off + vi);
+        v[k] = rtd::rotate(rot, f3(P[0], P[1], P[2]) * sc) + tr;
+        n[k] = rtd::rotate(rot, f3(N[0], N[1], N[2]));
+    }
+}
+
+__device__ __forceinline__ uint32_t ordered(float f) {  // float order -> unsigned order
+    uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__host__ __device__ inline float unordered(uint32_t u) {
+    u ^= (u >> 31) ? 0x80000000u : 0xFFFFFFFFu;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// ---- 1. boxes + scene bounds ----
+// bounds[0..2] = min of lo (ordered-integer form), bounds[3..5] = max of hi; status[0] = 1 on a bad vertex index
+__global__ void __launch_bounds__(kBlock) boxes_kernel(Sources S, uint32_t n, float4 *box_lo, float4 *box_hi, uint32_t *bounds,
+                                                       uint32_t *status) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    const float inf = __int_as_float(0x7f800000);
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    if (p < n) {
+        const uint32_t s = find_segment(S, p);
+        const uint32_t ref = S.seg_ref[s];
+        if (ref & kLeafBit) {
+            const MeshDev &m = S.meshes[ref & ~kLeafBit];
+            F3 v[3], nn[3];
+            uint32_t bad = 0;
+            mesh_face(S, m, p - S.seg_first[s], v, nn, &bad);
+            if (bad) status[0] = 1;
+            // Triangle::bounding_box (src/tracer/triangle.rs:80-105)
+            lo[0] = fmin_(v[0].x, fmin_(v[1].x, v[2].x)), hi[0] = fmax_(v[0].x, fmax_(v[1].x, v[2].x));
+            lo[1] = fmin_(v[0].y, fmin_(v[1].y, v[2].y)), hi[1] = fmax_(v[0].y, fmax_(v[1].y, v[2].y));
+            lo[2] = fmin_(v[0].z, fmin_(v[1].z, v[2].z)), hi[2] = fmax_(v[0].z, fmax_(v[1].z, v[2].z));
+        } else {
+            const SimpleDev &o = S.simples[ref];
+            for (int k = 0; k < 3; k++) lo[k] = o.box[k], hi[k] = o.box[4 + k];
+        }
+        box_lo[p] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+        box_hi[p] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    }
+    // block reduce (NaN-ignoring; an infinite or NaN box does not move the bounds)
+    __shared__ float red[6][kBlock / 64];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float a = (fabsf(lo[k]) < inf) ? lo[k] : inf, b = (fabsf(hi[k]) < inf) ? hi[k] : -inf;
+        for (int off = 32; off > 0; off >>= 1) {
+            a = fminf(a, __shfl_down(a, off, 64));
+            b = fmaxf(b, __shfl_down(b, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = a, red[3 + k][threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float v = red[k][0];
+        for (int w = 1; w < kBlock / 64; w++) v = (k < 3) ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+        if (k < 3)
+            atomicMin(&bounds[k], ordered(v));
+        else
+            atomicMax(&bounds[k], ordered(v));
+    }
+}
+
+// ---- 2. Morton codes ----
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {  // bit i -> bit 3i
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x1F00000000FFFFull;
+    x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+__global__ void __launch_bounds__(kBlock) morton_kernel(const float4 *box_lo, const float4 *box_hi, uint32_t n, const uint32_t *bounds,
+                                                        uint64_t *keys, uint32_t *vals) {
+    const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= n) return;
+    const float4 lo = box_lo[p], hi = box_hi[p];
+    const float c[3] = {0.5f * lo.x + 0.5f * hi.x, 0.5f * lo.y + 0.5f * hi.y, 0.5f * lo.z + 0.5f * hi.z};
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float b0 = unordered(bounds[k]), b1 = unordered(bounds[3 + k]);
+        const float ext = b1 - b0;
+        float u = (ext > 0.0f) ? (c[k] - b0) / ext : 0.0f;
+        u = fminf(fmaxf(u, 0.0f), 1.0f);  // (NaN -> 0)
+        q[k] = (uint32_t)fminf(u * 2097152.0f, 2097151.0f);
+    }
+    // Descending order in space and, among equal codes (the radix sort is stable), in declaration order: the reference
+    // visits the child with the larger coordinates first (right, then left), and its stable sort leaves the earlier
+    // declared of two coincident primitives on the left, where it is visited last and wins an exact tie
+    // (src/tracer/bvh.rs:42,148-155).  Array index = visit rank, so ranks here grow the same way.
+    const uint64_t code = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
+    keys[n - 1 - p] = ~code & 0x7FFFFFFFFFFFFFFFull;
+    vals[n - 1 - p] = p;
+}
+
+// ---- 3. records in sorted order ----
+__global__ void __launch_bounds__(kBlock) emit_kernel(Sources S, uint32_t n, const uint32_t *perm, const float4 *box_lo,
+                                                      const float4 *box_hi, float4 *prims, float4 *shade, float4 *leaf_lo,
+                                                      float4 *leaf_hi) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = perm[i];
+    const uint32_t s = find_segment(S, p);
+    const uint32_t ref = S.seg_ref[s];
+    float4 r0, r1, r2, n0, n1, n2;
+    if (ref & kLeafBit) {
+        const MeshDev &m = S.meshes[ref & ~kLeafBit];
+        F3 v[3], nn[3];
+        uint32_t bad = 0;
+        mesh_face(S, m, p - S.seg_first[s], v, nn, &bad);
+        const F3 e1 = v[1] - v[0], e2 = v[2] - v[0];
+        r0 = make_float4(v[0].x, v[0].y, v[0].z, e1.x);
+        r1 = make_float4(e1.y, e1.z, e2.x, e2.y);
+        r2 = make_float4(e2.z, 0.0f, __uint_as_float(m.meta), __uint_as_float(p));
+        n0 = make_float4(nn[0].x, nn[0].y, nn[0].z, 0.0f);
+        n1 = make_float4(nn[1].x, nn[1].y, nn[1].z, 0.0f);
+        n2 = make_float4(nn[2].x, nn[2].y, nn[2].z, 0.0f);
+    } else {
+        const float4 *q = (const float4 *)&S.simples[ref];
+        r0 = q[0], r1 = q[1], r2 = q[2], n0 = q[3], n1 = q[4], n2 = q[5];
+    }
+    prims[3 * (size_t)i + 0] = r0, prims[3 * (size_t)i + 1] = r1, prims[3 * (size_t)i + 2] = r2;
+    float4 *sh = shade + 6 * (size_t)i;
+    sh[0] = r0, sh[1] = r1, sh[2] = r2, sh[3] = n0, sh[4] = n1, sh[5] = n2;
+    leaf_lo[i] = box_lo[p];
+    leaf_hi[i] = box_hi[p];
+}
+
+// ---- 4. binary radix tree (Karras 2012) over sorted keys; equal keys are told apart by their position ----
+__device__ __forceinline__ int prefix_len(const uint64_t *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint64_t a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((uint32_t)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+// child / parent words: bit 31 set = leaf i, clear = internal node i
+__global__ void __launch_bounds__(kBlock) hierarchy_kernel(const uint64_t *keys, int n, uint2 *children, uint32_t *parent_of_node,
+                                                           uint32_t *parent_of_leaf) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (prefix_len(keys, n, i, i + 1) - prefix_len(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = prefix_len(keys, n, i, i - d);
+    int lmax = 2;
+    while (prefix_len(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (prefix_len(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = prefix_len(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (prefix_len(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? -1 : 0);
+    const int first = i < j ? i : j, last = i < j ? j : i;
+    const uint32_t left = (first == gamma) ? (kLeafBit | (uint32_t)gamma) : (uint32_t)gamma;
+    const uint32_t right = (last == gamma + 1) ? (kLeafBit | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+    children[i] = make_uint2(left, right);
+    if (left & kLeafBit) parent_of_leaf[gamma] = (uint32_t)i; else parent_of_node[gamma] = (uint32_t)i;
+    if (right & kLeafBit) parent_of_leaf[gamma + 1] = (uint32_t)i; else parent_of_node[gamma + 1] = (uint32_t)i;
+}
+
+// ---- 5. boxes bottom-up + the collapse table ----
+// Per internal node b:  node_lo/node_hi = its box;  cost[b] = (root, d2, d3, d4) with
+//   dj   = cheapest summed half area of wide-node root boxes below b when b's two subtrees share at most j slots
+//   root = half_area(b) + d4: b is the root of a wide node of its own
+// and split[b] packs, for j = 2, 3, 4, how many of the j slots go to the left child (2 bits each).
+__device__ __forceinline__ bool is_terminal(uint2 ch) { return (ch.x & ch.y & kLeafBit) != 0; }
+
+__device__ __forceinline__ float subtree_cost(uint32_t c, int k, const uint2 *children, const float4 *cost) {
+    if (c & kLeafBit) return 0.0f;
+    if (is_terminal(children[c])) return 0.0f;
+    const float4 t = cost[c];
+    float best = t.x;
+    if (k >= 2) best = fminf(best, t.y);
+    if (k >= 3) best = fminf(best, t.z);
+    if (k >= 4) best = fminf(best, t.w);
+    return best;
+}
+
+__global__ void __launch_bounds__(kBlock) fit_kernel(int n, const uint2 *children, const uint32_t *parent_of_node,
+                                                     const uint32_t *parent_of_leaf, const float4 *leaf_lo, const float4 *leaf_hi,
+                                                     float4 *node_lo, float4 *node_hi, float4 *cost, uint32_t *split,
+                                                     uint32_t *arrived) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    uint32_t cur = parent_of_leaf[i];
+    for (;;) {
+        __threadfence();  // what this thread wrote for the node below is visible before it is counted
+        const uint32_t before = atomicAdd(&arrived[cur], 1u);
+        if (before == 0) return;  // the sibling subtree is not done yet: its thread carries on
+        __threadfence();          // ... and what the sibling's thread wrote is read from memory, not from a stale line
+        const uint2 ch = children[cur];
+        float4 lo[2], hi[2];
+        const uint32_t c2[2] = {ch.x, ch.y};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (c2[k] & kLeafBit)
+                lo[k] = leaf_lo[c2[k] & ~kLeafBit], hi[k] = leaf_hi[c2[k] & ~kLeafBit];
+            else
+                lo[k] = node_lo[c2[k]], hi[k] = node_hi[c2[k]];
+        }
+        float4 blo = make_float4(fmin_(lo[0].x, lo[1].x), fmin_(lo[0].y, lo[1].y), fmin_(lo[0].z, lo[1].z), 0.0f);
+        float4 bhi = make_float4(fmax_(hi[0].x, hi[1].x), fmax_(hi[0].y, hi[1].y), fmax_(hi[0].z, hi[1].z), 0.0f);
+        if (is_terminal(ch)) {
+            // the box that guards a pair of primitives: Aabb::surrounding_box pads by EPSILON (src/tracer/cube.rs:179-193)
+            blo.x -= kEps, blo.y -= kEps, blo.z -= kEps;
+            bhi.x += kEps, bhi.y += kEps, bhi.z += kEps;
+        }
+        node_lo[cur] = blo;
+        node_hi[cur] = bhi;
+        float d[3];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 2; j <= 4; j++) {
+            float best = __int_as_float(0x7f800000);
+            int best_k = 1;
+            for (int k = 1; k < j; k++) {
+                const float v = subtree_cost(ch.x, k, children, cost) + subtree_cost(ch.y, j - k, children, cost);
+                if (v < best) best = v, best_k = k;
+            }
+            d[j - 2] = best;
+            packed |= (uint32_t)best_k << (2 * (j - 2));
+        }
+        const float dx = bhi.x - blo.x, dy = bhi.y - blo.y, dz = bhi.z - blo.z;
+        float area = dx * dy + dy * dz + dz * dx;
+        if (!(area >= 0.0f)) area = 0.0f;  // a NaN box must not poison the table
+        cost[cur] = make_float4(area + d[2], d[0], d[1], d[2]);
+        split[cur] = packed;
+        if (cur == 0) return;
+        cur = parent_of_node[cur];
+    }
+}
+
+// ---- 6. collapse, one level of the wide tree per launch ----
+struct WideSlot {
+    uint32_t word;   // child word for leaves; binary node id for internal slots
+    uint32_t inner;  // 1: `word` is a binary node that roots a wide node of the next level
+    float4 lo, hi;
+};
+
+// Slots of the wide node rooted at binary node b (not a terminal): b's two subtrees in at most 4 slots by the table.
+__device__ __forceinline__ int wide_slots(uint32_t b, const uint2 *children, const float4 *cost, const uint32_t *split,
+                                          const float4 *leaf_lo, const float4 *leaf_hi, const float4 *node_lo,
+                                          const float4 *node_hi, bool greedy, WideSlot out[4]) {
+    int n_out = 0;
+    if (greedy) {
+        // dissolve the child with the largest box first (the simpler rule; kept for comparison)
+        uint32_t c[4];
+        int n = 2;
+        const uint2 ch = children[b];
+        c[0] = ch.x, c[1] = ch.y;
+        for (;;) {
+            int best = -1;
+            float best_area = -1.0f;
+            for (int i = 0; i < n; i++) {
+                if ((c[i] & kLeafBit) || is_terminal(children[c[i]])) continue;
+                const float4 l = node_lo[c[i]], h = node_hi[c[i]];
+                const float dx = h.x - l.x, dy = h.y - l.y, dz = h.z - l.z;
+                const float a = dx * dy + dy * dz + dz * dx;
+                if (a > best_area) best_area = a, best = i;
+            }
+            if (best < 0 || n >= 4) break;
+            const uint2 k = children[c[best]];
+            for (int i = n; i > best + 1; i--) c[i] = c[i - 1];  // keep left-to-right order
+            c[best] = k.x, c[best + 1] = k.y;
+            n++;
+        }
+        for (int i = 0; i < n; i++) {
+            WideSlot &o = out[n_out++];
+            if (c[i] & kLeafBit) {
+                const uint32_t leaf = c[i] & ~kLeafBit;
+                o.word = RT_CHILD_LEAF | leaf, o.inner = 0, o.lo = leaf_lo[leaf], o.hi = leaf_hi[leaf];
+            } else {
+                const uint2 k = children[c[i]];
+                o.lo = node_lo[c[i]], o.hi = node_hi[c[i]];
+                if (is_terminal(k))
+                    o.word = RT_CHILD_LEAF | (1u << 28) | (k.x & ~kLeafBit), o.inner = 0;
+                else
+                    o.word = c[i], o.inner = 1;
+            }
+        }
+        return n_out;
+    }
+    // (node, slots it may use) pairs still to be placed, left to right
+    uint32_t st_node[6];
+    int st_k[6];
+    int sp = 0;
+    {
+        const uint2 ch = children[b];
+        const int k = (int)((split[b] >> 4) & 3u);  // j = 4
+        st_node[sp] = ch.y, st_k[sp] = 4 - k, sp++;
+        st_node[sp] = ch.x, st_k[sp] = k, sp++;
+    }
+    while (sp > 0) {
+        sp--;
+        const uint32_t c = st_node[sp];
+        const int k = st_k[sp];
+        if (k <= 0) continue;
+        WideSlot &o = out[n_out];
+        if (c & kLeafBit) {
+            const uint32_t leaf = c & ~kLeafBit;
+            o.word = RT_CHILD_LEAF | leaf, o.inner = 0, o.lo = leaf_lo[leaf], o.hi = leaf_hi[leaf];
+            n_out++;
+            continue;
+        }
+        const uint2 ch = children[c];
+        if (is_terminal(ch)) {
+            o.word = RT_CHILD_LEAF | (1u << 28) | (ch.x & ~kLeafBit), o.inner = 0, o.lo = node_lo[c], o.hi = node_hi[c];
+            n_out++;
+            continue;
+        }
+        const float4 t = cost[c];
+        float best = t.x;
+        int best_j = 1;
+        if (k >= 2 && t.y < best) best = t.y, best_j = 2;
+        if (k >= 3 && t.z < best) best = t.z, best_j = 3;
+        if (k >= 4 && t.w < best) best = t.w, best_j = 4;
+        if (best_j == 1) {
+            o.word = c, o.inner = 1, o.lo = node_lo[c], o.hi = node_hi[c];
+            n_out++;
+            continue;
+        }
+        const int kl = (int)((split[c] >> (2 * (best_j - 2))) & 3u);
+        st_node[sp] = ch.y, st_k[sp] = best_j - kl, sp++;
+        st_node[sp] = ch.x, st_k[sp] = kl, sp++;
+    }
+    return n_out;
+}
+
+// queue_in[0 .. count) = binary nodes whose wide nodes are level_begin + position; their inner children get the wide
+// indices that `alloc` hands out from level_begin + count on, and are written to queue_out at (index - level_begin - count).
+__global__ void __launch_bounds__(kBlock) collapse_kernel(const uint32_t *queue_in, uint32_t count, uint32_t level_begin,
+                                                          uint32_t *queue_out, uint32_t *alloc, const uint2 *children,
+                                                          const float4 *cost, const uint32_t *split, const float4 *leaf_lo,
+                                                          const float4 *leaf_hi, const float4 *node_lo, const float4 *node_hi,
+                                                          int greedy, float4 *wide) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    WideSlot slots[4];
+    int n_slots = 0;
+    uint32_t inner = 0;
+    if (t < count) {
+        n_slots = wide_slots(queue_in[t], children, cost, split, leaf_lo, leaf_hi, node_lo, node_hi, greedy != 0, slots);
+        for (int i = 0; i < n_slots; i++) inner += slots[i].inner;
+    }
+    // exclusive prefix sum of `inner` over the block, one reservation per block
+    __shared__ uint32_t wave_sum[kBlock / 64];
+    __shared__ uint32_t block_base;
+    uint32_t incl = inner;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += v;
+    }
+    if ((threadIdx.x & 63) == 63) wave_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < kBlock / 64; w++) {
+            const uint32_t v = wave_sum[w];
+            wave_sum[w] = total;
+            total += v;
+        }
+        block_base = total ? atomicAdd(alloc, total) : 0u;
+    }
+    __syncthreads();
+    if (t >= count) return;
+    uint32_t next = block_base + wave_sum[threadIdx.x >> 6] + (incl - inner);
+    float bx[6][4];
+    uint32_t words[4] = {RT_CHILD_NONE, RT_CHILD_NONE, RT_CHILD_NONE, RT_CHILD_NONE};
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) bx[a][i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i >= n_slots) continue;
+        bx[0][i] = slots[i].lo.x, bx[1][i] = slots[i].lo.y, bx[2][i] = slots[i].lo.z;
+        bx[3][i] = slots[i].hi.x, bx[4][i] = slots[i].hi.y, bx[5][i] = slots[i].hi.z;
+        if (slots[i].inner) {
+            words[i] = next;
+            queue_out[next - (level_begin + count)] = slots[i].word;
+            next++;
+        } else {
+            words[i] = slots[i].word;
+        }
+    }
+    float4 *dst = wide + (size_t)(level_begin + t) * RT_NODE_FLOAT4S;
+#pragma unroll
+    for (int a = 0; a < 6; a++) dst[a] = make_float4(bx[a][0], bx[a][1], bx[a][2], bx[a][3]);
+    dst[6] = make_float4(__uint_as_float(words[0]), __uint_as_float(words[1]), __uint_as_float(words[2]), __uint_as_float(words[3]));
+    dst[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// the whole tree of a scene with one or two primitives: one wide node, one leaf slot
+__global__ void tiny_tree_kernel(int n, const float4 *leaf_lo, const float4 *leaf_hi, float4 *node_lo, float4 *node_hi,
+                                 float4 *wide) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float4 lo = leaf_lo[0], hi = leaf_hi[0];
+    if (n == 2) {
+        const float4 l1 = leaf_lo[1], h1 = leaf_hi[1];
+        lo = make_float4(fmin_(lo.x, l1.x) - kEps, fmin_(lo.y, l1.y) - kEps, fmin_(lo.z, l1.z) - kEps, 0.0f);
+        hi = make_float4(fmax_(hi.x, h1.x) + kEps, fmax_(hi.y, h1.y) + kEps, fmax_(hi.z, h1.z) + kEps, 0.0f);
+    }
+    node_lo[0] = lo, node_hi[0] = hi;
+    wide[0] = make_float4(lo.x, 0, 0, 0), wide[1] = make_float4(lo.y, 0, 0, 0), wide[2] = make_float4(lo.z, 0, 0, 0);
+    wide[3] = make_float4(hi.x, 0, 0, 0), wide[4] = make_float4(hi.y, 0, 0, 0), wide[5] = make_float4(hi.z, 0, 0, 0);
+    wide[6] = make_float4(__uint_as_float(RT_CHILD_LEAF | ((uint32_t)(n - 1) << 28)), __uint_as_float(RT_CHILD_NONE),
+                          __uint_as_float(RT_CHILD_NONE), __uint_as_float(RT_CHILD_NONE));
+    wide[7] = make_float4(0, 0, 0, 0);
+}
+
+#define GB_HIP(call)                                                              \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            err = std::string(#call) + ": " + hipGetErrorString(e_);              \
+            return RT_ERR_DEVICE;                                                 \
+        }                                                                         \
+    } while (0)
+
+// One device allocation cut into 256-byte aligned pieces (the build's temporaries).
+struct Arena {
+    char *base = nullptr;
+    size_t size = 0, used = 0;
+    ~Arena() {
+        if (base) (void)hipFree(base);
+    }
+    static size_t pad(size_t b) { return (b + 255) & ~(size_t)255; }
+    template <class T>
+    T *take(size_t count) {
+        T *p = (T *)(base + used);
+        used += pad(count * sizeof(T));
+        return p;
+    }
+};
+
+// Host arrays go to a device pool in the order they are added; small ones are gathered in a staging vector so that
+// a scene of thousands of small meshes costs a few copies, large ones are copied straight from the caller's memory.
+struct PoolUpload {
+    struct Piece {
+        const void *src;
+        size_t bytes, offset;
+    };
+    std::vector<Piece> pieces;
+    size_t total = 0;
+    size_t add(const void *src, size_t bytes) {
+        const size_t off = total;
+        pieces.push_back(Piece{src, bytes, off});
+        total += bytes;
+        return off;
+    }
+    int run(char *dst, std::string &err) const {
+        constexpr size_t kSmall = 4u << 20, kFlush = 64u << 20;
+        std::vector<char> stage;
+        size_t stage_off = 0;
+        auto flush = [&]() -> int {
+            if (stage.empty()) return RT_OK;
+            GB_HIP(hipMemcpy(dst + stage_off, stage.data(), stage.size(), hipMemcpyHostToDevice));
+            stage.clear();
+            return RT_OK;
+        };
+        for (const Piece &p : pieces) {
+            if (p.bytes == 0) continue;
+            if (p.bytes >= kSmall) {
+                int rc = flush();
+                if (rc) return rc;
+                GB_HIP(hipMemcpy(dst + p.offset, p.src, p.bytes, hipMemcpyHostToDevice));
+                continue;
+            }
+            if (stage.empty()) stage_off = p.offset;
+            stage.insert(stage.end(), (const char *)p.src, (const char *)p.src + p.bytes);
+            if (stage.size() >= kFlush) {
+                int rc = flush();
+                if (rc) return rc;
+            }
+        }
+        return flush();
+    }
+};
+
+struct PtrKey {
+    const void *a, *b;
+    uint64_t n;
+    bool operator==(const PtrKey &o) const { return a == o.a && b == o.b && n == o.n; }
+};
+struct PtrKeyHash {
+    size_t operator()(const PtrKey &k) const {
+        return std::hash<const void *>()(k.a) ^ (std::hash<const void *>()(k.b) * 1000003u) ^ (size_t)(k.n * 0x9E3779B97F4A7C15ull);
+    }
+};
+
+double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+}  // namespace
+
+void DeviceBuild::release() {
+    if (nodes) (void)hipFree(nodes);
+    if (prims) (void)hipFree(prims);
+    if (shade_records) (void)hipFree(shade_records);
+    nodes = prims = shade_records = nullptr;
+}
+
+int build_device_scene(const RtSceneDesc *d, DeviceBuild &out, std::string &err) {
+    const auto t_start = std::chrono::steady_clock::now();
+    const bool debug = std::getenv("RTCORE_DEBUG_TREE") != nullptr;
+    uint64_t total = 0;
+    {
+        int rc = check_scene_desc(d, total, err, /*check_indices=*/false);  // vertex indices are checked on the device
+        if (rc) return rc;
+    }
+    const uint32_t n = (uint32_t)total;
+
+    // ---- sources: one segment per object; mesh arrays that several objects share are uploaded once
+    std::vector<uint32_t> seg_first(d->n_objects), seg_ref(d->n_objects);
+    std::vector<MeshDev> meshes;
+    std::vector<SimpleDev> simples;
+    PoolUpload pos_pool, nrm_pool, idx_pool;
+    std::unordered_map<PtrKey, uint64_t, PtrKeyHash> vtx_seen, idx_seen;
+    uint64_t id = 0, n_triangles = 0;
+    for (uint64_t i = 0; i < d->n_objects; i++) {
+        const RtObject &o = d->objects[i];
+        seg_first[i] = (uint32_t)id;
+        if (o.type == RT_OBJ_MESH) {
+            const RtMesh &m = d->meshes[o.mesh];
+            MeshDev md;
+            std::memset(&md, 0, sizeof(md));
+            mesh_rotor(m, md.rot);
+            for (int k = 0; k < 3; k++) md.scale[k] = m.scale[k], md.tr[k] = m.translation[k];
+            md.meta = RT_PRIM_TRIANGLE | (m.cull_backface ? 0u : RT_PRIM_FLAG) | ((uint32_t)o.material << RT_PRIM_MAT_SHIFT);
+            md.n_vertices = (uint32_t)std::min<uint64_t>(m.n_vertices, 0xFFFFFFFFull);
+            const PtrKey vk{m.positions, m.normals, m.n_vertices}, ik{m.indices, nullptr, m.n_faces};
+            auto vit = vtx_seen.find(vk);
+            if (vit == vtx_seen.end()) {
+                const uint64_t off = pos_pool.add(m.positions, m.n_vertices * 12) / 12;
+                nrm_pool.add(m.normals, m.n_vertices * 12);
+                vit = vtx_seen.emplace(vk, off).first;
+            }
+            auto iit = idx_seen.find(ik);
+            if (iit == idx_seen.end()) iit = idx_seen.emplace(ik, idx_pool.add(m.indices, m.n_faces * 12) / 12).first;
+            md.vtx_off = vit->second;
+            md.face_off = iit->second;
+            seg_ref[i] = kLeafBit | (uint32_t)meshes.size();
+            meshes.push_back(md);
+            id += m.n_faces;
+            n_triangles += m.n_faces;
+        } else {
+            SimpleDev sd;
+            std::memset(&sd, 0, sizeof(sd));
+            float box[6];
+            simple_object_record(o, (uint32_t)id, sd.rec, sd.nrm, box);
+            for (int k = 0; k < 3; k++) sd.box[k] = box[k], sd.box[4 + k] = box[3 + k];
+            seg_ref[i] = (uint32_t)simples.size();
+            simples.push_back(sd);
+            if (o.type == RT_OBJ_TRIANGLE) n_triangles++;
+            id += 1;
+        }
+    }
+
+    // ---- device memory: outputs of their own, everything else from one arena
+    DeviceBuild B;
+    struct Guard {  // frees the outputs unless the build completes
+        DeviceBuild *b;
+        ~Guard() {
+            if (b) b->release();
+        }
+    } guard{&B};
+    B.prims_bytes = (size_t)n * 48 + 128;  // (spare bytes: see the traversal's record fetches)
+    B.shade_bytes = (size_t)n * 96 + 128;
+    GB_HIP(hipMalloc(&B.prims, B.prims_bytes));
+    GB_HIP(hipMalloc(&B.shade_records, B.shade_bytes));
+
+    size_t sort_tmp_bytes = 0;
+    GB_HIP(rocprim::radix_sort_pairs(nullptr, sort_tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr,
+                                     (uint32_t *)nullptr, n, 0, 63, (hipStream_t)0));
+    const size_t n_inner = n > 1 ? n - 1 : 1;
+    const size_t max_wide = n_inner;
+    Arena A;
+    {
+        auto P = Arena::pad;
+        A.size = P(seg_first.size() * 4) * 2 + P(meshes.size() * sizeof(MeshDev)) + P(simples.size() * sizeof(SimpleDev)) +
+                 P(pos_pool.total) + P(nrm_pool.total) + P(idx_pool.total) + 2 * P((size_t)n * 16) /*boxes*/ +
+                 2 * P((size_t)n * 8) + 2 * P((size_t)n * 4) /*keys, vals*/ + P(sort_tmp_bytes) + 2 * P((size_t)n * 16) /*leaf boxes*/ +
+                 P(n_inner * 8) + 2 * P((size_t)n * 4) /*children, parents*/ + 3 * P(n_inner * 16) /*node boxes, cost*/ +
+                 2 * P(n_inner * 4) /*split, arrived*/ + 2 * P(n_inner * 4) /*queues*/ + P(max_wide * 128) + P(256) + 4096;
+        GB_HIP(hipMalloc((void **)&A.base, A.size));
+    }
+    uint32_t *d_seg_first = A.take<uint32_t>(seg_first.size()), *d_seg_ref = A.take<uint32_t>(seg_ref.size());
+    MeshDev *d_meshes = A.take<MeshDev>(meshes.size());
+    SimpleDev *d_simples = A.take<SimpleDev>(simples.size());
+    char *d_pos = A.take<char>(pos_pool.total), *d_nrm = A.take<char>(nrm_pool.total), *d_idx = A.take<char>(idx_pool.total);
+    float4 *box_lo = A.take<float4>(n), *box_hi = A.take<float4>(n);
+    uint64_t *keys_a = A.take<uint64_t>(n), *keys_b = A.take<uint64_t>(n);
+    uint32_t *vals_a = A.take<uint32_t>(n), *vals_b = A.take<uint32_t>(n);
+    char *sort_tmp = A.take<char>(sort_tmp_bytes);
+    float4 *leaf_lo = A.take<float4>(n), *leaf_hi = A.take<float4>(n);
+    uint2 *children = A.take<uint2>(n_inner);
+    uint32_t *parent_of_node = A.take<uint32_t>(n), *parent_of_leaf = A.take<uint32_t>(n);
+    float4 *node_lo = A.take<float4>(n_inner), *node_hi = A.take<float4>(n_inner), *cost = A.take<float4>(n_inner);
+    uint32_t *split = A.take<uint32_t>(n_inner), *arrived = A.take<uint32_t>(n_inner);
+    uint32_t *queue_a = A.take<uint32_t>(n_inner), *queue_b = A.take<uint32_t>(n_inner);
+    float4 *wide = A.take<float4>(max_wide * 8);
+    uint32_t *scalars = A.take<uint32_t>(64);  // [0..5] bounds, [8] status, [9] wide-node counter
+    if (A.used > A.size) {
+        err = "internal: build arena too small";
+        return RT_ERR_INTERNAL;
+    }
+
+    // ---- uploads
+    GB_HIP(hipMemcpy(d_seg_first, seg_first.data(), seg_first.size() * 4, hipMemcpyHostToDevice));
+    GB_HIP(hipMemcpy(d_seg_ref, seg_ref.data(), seg_ref.size() * 4, hipMemcpyHostToDevice));
+    if (!meshes.empty()) GB_HIP(hipMemcpy(d_meshes, meshes.data(), meshes.size() * sizeof(MeshDev), hipMemcpyHostToDevice));
+    if (!simples.empty()) GB_HIP(hipMemcpy(d_simples, simples.data(), simples.size() * sizeof(SimpleDev), hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = pos_pool.run(d_pos, err)) || (rc = nrm_pool.run(d_nrm, err)) || (rc = idx_pool.run(d_idx, err))) return rc;
+    {
+        uint32_t init[64];
+        std::memset(init, 0, sizeof(init));
+        for (int k = 0; k < 3; k++) init[k] = 0xFFFFFFFFu, init[3 + k] = 0u;
+        GB_HIP(hipMemcpy(scalars, init, sizeof(init), hipMemcpyHostToDevice));
+    }
+    const double ms_upload = ms_since(t_start);
+
+    // ---- device stages
+    Sources S{d_seg_first, d_seg_ref, (uint32_t)seg_first.size(), d_meshes, d_simples, (const float *)d_pos, (const float *)d_nrm,
+              (const uint32_t *)d_idx};
+    const hipStream_t stream = 0;
+    const uint32_t blocks_n = (n + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(boxes_kernel, dim3(blocks_n), dim3(kBlock), 0, stream, S, n, box_lo, box_hi, scalars, scalars + 8);
+    hipLaunchKernelGGL(morton_kernel, dim3(blocks_n), dim3(kBlock), 0, stream, box_lo, box_hi, n, scalars, keys_a, vals_a);
+    GB_HIP(hipGetLastError());
+    GB_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys_a, keys_b, vals_a, vals_b, n, 0, 63, stream));
+    hipLaunchKernelGGL(emit_kernel, dim3(blocks_n), dim3(kBlock), 0, stream, S, n, vals_b, box_lo, box_hi, (float4 *)B.prims,
+                       (float4 *)B.shade_records, leaf_lo, leaf_hi);
+    GB_HIP(hipGetLastError());
+
+    uint32_t n_wide = 0, depth = 0;
+    const char *collapse = std::getenv("RTCORE_COLLAPSE");
+    const int greedy = (collapse && std::strcmp(collapse, "greedy") == 0) ? 1 : 0;
+    if (n <= 2) {
+        hipLaunchKernelGGL(tiny_tree_kernel, dim3(1), dim3(64), 0, stream, (int)n, leaf_lo, leaf_hi, node_lo, node_hi, wide);
+        GB_HIP(hipGetLastError());
+        n_wide = 1, depth = 1;
+    } else {
+        GB_HIP(hipMemsetAsync(arrived, 0, n_inner * 4, stream));
+        hipLaunchKernelGGL(hierarchy_kernel, dim3((n - 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, keys_b, (int)n, children,
+                           parent_of_node, parent_of_leaf);
+        hipLaunchKernelGGL(fit_kernel, dim3(blocks_n), dim3(kBlock), 0, stream, (int)n, children, parent_of_node, parent_of_leaf,
+                           leaf_lo, leaf_hi, node_lo, node_hi, cost, split, arrived);
+        GB_HIP(hipGetLastError());
+        // level 0 is the root (binary node 0; not a terminal because n > 2)
+        const uint32_t zero = 0, one = 1;
+        GB_HIP(hipMemcpyAsync(queue_a, &zero, 4, hipMemcpyHostToDevice, stream));
+        GB_HIP(hipMemcpyAsync(scalars + 9, &one, 4, hipMemcpyHostToDevice, stream));
+        uint32_t level_begin = 0, count = 1;
+        uint32_t *qin = queue_a, *qout = queue_b;
+        while (count) {
+            if (depth > 4096) {
+                err = "internal: wide tree deeper than 4096 levels";
+                return RT_ERR_INTERNAL;
+            }
+            hipLaunchKernelGGL(collapse_kernel, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, qin, count, level_begin,
+                               qout, scalars + 9, children, cost, split, leaf_lo, leaf_hi, node_lo, node_hi, greedy, wide);
+            GB_HIP(hipGetLastError());
+            uint32_t allocated = 0;
+            GB_HIP(hipMemcpy(&allocated, scalars + 9, 4, hipMemcpyDeviceToHost));  // (synchronises)
+            depth++;
+            level_begin += count;
+            if (allocated < level_begin || allocated > max_wide) {
+                err = "internal: wide-node counter out of range";
+                return RT_ERR_INTERNAL;
+            }
+            count = allocated - level_begin;
+            std::swap(qin, qout);
+        }
+        n_wide = level_begin;
+    }
+    uint32_t host_scalars[16];
+    float4 root_box[2];
+    GB_HIP(hipMemcpy(host_scalars, scalars, sizeof(host_scalars), hipMemcpyDeviceToHost));
+    GB_HIP(hipMemcpy(&root_box[0], node_lo, 16, hipMemcpyDeviceToHost));
+    GB_HIP(hipMemcpy(&root_box[1], node_hi, 16, hipMemcpyDeviceToHost));
+    if (host_scalars[8]) {
+        err = "a mesh has a vertex index out of range";
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    if ((uint64_t)n_wide >= (1ull << 25)) {  // kernels address nodes with 32-bit byte offsets
+        err = "too many tree nodes";
+        return RT_ERR_INVALID_ARGUMENT;
+    }
+    B.nodes_bytes = (size_t)n_wide * 128 + 128;
+    GB_HIP(hipMalloc(&B.nodes, B.nodes_bytes));
+    GB_HIP(hipMemcpy(B.nodes, wide, (size_t)n_wide * 128, hipMemcpyDeviceToDevice));
+    GB_HIP(hipDeviceSynchronize());
+
+    B.n_prims = n, B.n_triangles = n_triangles, B.n_nodes = n_wide, B.n_binary_nodes = n > 1 ? n - 1 : 1;
+    B.wide_depth = depth;
+    B.max_stack = 3 * depth + 4;
+    B.root_lo[0] = root_box[0].x, B.root_lo[1] = root_box[0].y, B.root_lo[2] = root_box[0].z;
+    B.root_hi[0] = root_box[1].x, B.root_hi[1] = root_box[1].y, B.root_hi[2] = root_box[1].z;
+    B.ms_upload = ms_upload;
+    B.ms_total = ms_since(t_start);
+    if (debug)
+        std::fprintf(stderr, "[rtcore] device build: %u primitives, %u wide nodes, %u levels, upload %.1f ms, total %.1f ms\n", n, n_wide,
+                     depth, B.ms_upload, B.ms_total);
+    out = B;
+    guard.b = nullptr;
+    return RT_OK;
+}
+
+}  // namespace rtcore

@@ -18,6 +18,7 @@
 // a pass needs no host synchronisation.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -32,6 +33,7 @@
 #include "rt_traverse.hpp"
 #include "rt_pool.hpp"
 #include "scene_build.hpp"
+#include "gpu_build.hpp"
 
 using namespace rtd;
 
@@ -620,6 +622,8 @@ struct RtScene {
     size_t events_used = 0;
     RtStats stats{};
     uint64_t device_bytes = 0;
+    int builder = RT_BUILD_EXACT;  // which build made the tree
+    double build_ms = 0.0;         // host clock of that build (replicas: of the one build they share)
 };
 
 namespace {
@@ -909,8 +913,10 @@ int rt_init(int device) {
     return scratch_base(cur, &base);  // the no-allocation entry point's work memory on this device
 }
 
-// Uploads a built scene to the CURRENT device.  `h` keeps its arrays (several replicas may be made from one build).
-static int upload_scene(const rtcore::HostScene &h, RtScene **out) {
+// Puts a built scene on the CURRENT device.  `h` keeps its arrays (several replicas may be made from one build).
+// The tree and the primitive records come from `h` (host build), from `dev` (device build on this device; the
+// scene takes the allocations over) or from `peer` (a scene on another or the same device: device-to-device copies).
+static int upload_scene(const rtcore::HostScene &h, rtcore::DeviceBuild *dev, const RtScene *peer, RtScene **out) {
     std::unique_ptr<RtScene> s(new RtScene());
     // metadata only: the device copies are what the kernels read
     s->host.env_w = h.env_w, s->host.env_h = h.env_h;
@@ -933,9 +939,28 @@ static int upload_scene(const rtcore::HostScene &h, RtScene **out) {
         s->device_bytes += bytes;
         return RT_OK;
     };
-    if ((rc = upload(s->nodes, h.nodes.data(), h.nodes.size() * 4))) return rc;
-    if ((rc = upload(s->prims, h.prims.data(), h.prims.size() * 4))) return rc;
-    if ((rc = upload(s->shade_records, h.shade_records.data(), h.shade_records.size() * 4))) return rc;
+    if (dev) {
+        s->nodes.p = dev->nodes, s->nodes.bytes = dev->nodes_bytes;
+        s->prims.p = dev->prims, s->prims.bytes = dev->prims_bytes;
+        s->shade_records.p = dev->shade_records, s->shade_records.bytes = dev->shade_bytes;
+        dev->nodes = dev->prims = dev->shade_records = nullptr;
+        s->device_bytes += h.n_nodes * 128 + h.n_prims * (48 + 96);
+    } else if (peer) {
+        auto copy = [&](DevBuf &b, const DevBuf &from) -> int {
+            if (!from.p) return RT_OK;
+            int r = b.ensure(from.bytes);
+            if (r) return r;
+            RT_HIP(hipMemcpyPeer(b.p, s->device, from.p, peer->device, from.bytes));
+            return RT_OK;
+        };
+        if ((rc = copy(s->nodes, peer->nodes)) || (rc = copy(s->prims, peer->prims)) || (rc = copy(s->shade_records, peer->shade_records)))
+            return rc;
+        s->device_bytes += h.n_nodes * 128 + h.n_prims * (48 + 96);
+    } else {
+        if ((rc = upload(s->nodes, h.nodes.data(), h.nodes.size() * 4))) return rc;
+        if ((rc = upload(s->prims, h.prims.data(), h.prims.size() * 4))) return rc;
+        if ((rc = upload(s->shade_records, h.shade_records.data(), h.shade_records.size() * 4))) return rc;
+    }
     if ((rc = upload(s->materials, h.materials.data(), h.materials.size() * sizeof(RtDevMaterial)))) return rc;
     if ((rc = upload(s->env, h.env.data(), h.env.size() * 4))) return rc;
     RtSceneView &v = s->view;
@@ -954,7 +979,18 @@ static int upload_scene(const rtcore::HostScene &h, RtScene **out) {
     return RT_OK;
 }
 
-int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
+// RT_BUILD_DEFAULT: the environment decides (RTCORE_BUILD=gpu selects the device build), else the exact host build.
+static int resolve_builder(int builder) {
+    if (builder == RT_BUILD_DEFAULT) {
+        const char *e = std::getenv("RTCORE_BUILD");
+        return (e && (std::strcmp(e, "gpu") == 0 || std::strcmp(e, "device") == 0)) ? RT_BUILD_DEVICE : RT_BUILD_EXACT;
+    }
+    return builder;
+}
+
+int rt_scene_create(const RtSceneDesc *desc, RtScene **out) { return rt_scene_create_with(desc, RT_BUILD_DEFAULT, out); }
+
+int rt_scene_create_with(const RtSceneDesc *desc, int builder, RtScene **out) {
     int dev = 0;
     if (!out) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
@@ -962,13 +998,21 @@ int rt_scene_create(const RtSceneDesc *desc, RtScene **out) {
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
         return fail(RT_ERR_DEVICE, "no HIP device is visible; the core has no CPU path");
     RT_HIP(hipGetDevice(&dev));
-    return rt_scene_create_replicas(desc, &dev, 1, out);
+    return rt_scene_create_replicas_with(desc, builder, &dev, 1, out);
 }
 
-// One host build, one upload per entry of `devices` (a device may be named more than once).
 int rt_scene_create_replicas(const RtSceneDesc *desc, const int *devices, int n, RtScene **out) {
+    return rt_scene_create_replicas_with(desc, RT_BUILD_DEFAULT, devices, n, out);
+}
+
+// One build, one replica per entry of `devices` (a device may be named more than once).  The host build is uploaded
+// to every device; the device build runs on devices[0] and the other replicas are device-to-device copies of it.
+int rt_scene_create_replicas_with(const RtSceneDesc *desc, int builder, const int *devices, int n, RtScene **out) {
     if (!desc || !out || !devices || n < 1) return fail(RT_ERR_INVALID_ARGUMENT, "null argument");
     for (int i = 0; i < n; i++) out[i] = nullptr;
+    if (builder != RT_BUILD_DEFAULT && builder != RT_BUILD_EXACT && builder != RT_BUILD_DEVICE)
+        return fail(RT_ERR_INVALID_ARGUMENT, "unknown builder");
+    builder = resolve_builder(builder);
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0)
         return fail(RT_ERR_DEVICE, "no HIP device is visible; the core has no CPU path");
@@ -976,14 +1020,35 @@ int rt_scene_create_replicas(const RtSceneDesc *desc, const int *devices, int n,
         if (devices[i] < 0 || devices[i] >= n_dev) return fail(RT_ERR_INVALID_ARGUMENT, "device index out of range");
     int before = 0;
     RT_HIP(hipGetDevice(&before));
+    const auto t0 = std::chrono::steady_clock::now();
     rtcore::HostScene h;
+    rtcore::DeviceBuild db;
     std::string err;
-    int rc = rtcore::build_host_scene(desc, h, err);
-    if (rc) return fail(rc, err);
+    int rc;
+    if (builder == RT_BUILD_DEVICE) {
+        if (hipSetDevice(devices[0]) != hipSuccess) return fail(RT_ERR_DEVICE, "hipSetDevice failed");
+        rc = rtcore::fill_materials_camera_env(desc, h, err);
+        if (rc == RT_OK) rc = rtcore::build_device_scene(desc, db, err);
+        if (rc) {
+            (void)hipSetDevice(before);
+            return fail(rc, err);
+        }
+        h.n_prims = db.n_prims, h.n_triangles = db.n_triangles, h.n_nodes = db.n_nodes, h.n_binary_nodes = db.n_binary_nodes;
+        h.wide_depth = db.wide_depth, h.max_stack = db.max_stack;
+        for (int k = 0; k < 3; k++) h.root_lo[k] = db.root_lo[k], h.root_hi[k] = db.root_hi[k];
+    } else {
+        rc = rtcore::build_host_scene(desc, h, err);
+        if (rc) return fail(rc, err);
+    }
+    const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     for (int i = 0; i < n && rc == RT_OK; i++) {
         if (hipSetDevice(devices[i]) != hipSuccess) rc = fail(RT_ERR_DEVICE, "hipSetDevice failed");
-        if (rc == RT_OK) rc = upload_scene(h, &out[i]);
+        if (rc == RT_OK)
+            rc = upload_scene(h, (builder == RT_BUILD_DEVICE && i == 0) ? &db : nullptr,
+                              (builder == RT_BUILD_DEVICE && i > 0) ? out[0] : nullptr, &out[i]);
+        if (rc == RT_OK) out[i]->builder = builder, out[i]->build_ms = build_ms;
     }
+    db.release();  // (only holds something when the first upload failed)
     (void)hipSetDevice(before);
     if (rc != RT_OK) {
         const std::string msg = g_error;
@@ -1012,6 +1077,7 @@ int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info) {
     info->primitive_bytes = RT_PRIM_FLOAT4S * 16;
     info->device_bytes = (h.nodes.size() + h.prims.size() + h.shade_records.size() + h.env.size()) * 4 +
                          h.materials.size() * sizeof(RtDevMaterial);
+    info->builder = RT_BUILD_EXACT;
     for (int k = 0; k < 3; k++) info->bounds_min[k] = h.root_lo[k], info->bounds_max[k] = h.root_hi[k];
     return RT_OK;
 }
@@ -1036,6 +1102,8 @@ int rt_scene_info(const RtScene *s, RtSceneInfo *info) {
     info->node_bytes = RT_NODE_FLOAT4S * 16;
     info->primitive_bytes = RT_PRIM_FLOAT4S * 16;
     info->device_bytes = s->device_bytes;
+    info->builder = (uint32_t)s->builder;
+    info->build_ms = s->build_ms;
     for (int k = 0; k < 3; k++) info->bounds_min[k] = s->host.root_lo[k], info->bounds_max[k] = s->host.root_hi[k];
     return RT_OK;
 }

@@ -693,14 +693,8 @@ void parallel_ranges(uint64_t n, F fn) {
     for (auto &t : pool) t.join();
 }
 
-int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
-    const bool debug_tree = std::getenv("RTCORE_DEBUG_TREE") != nullptr;
-    auto t_phase = std::chrono::steady_clock::now();
-    auto phase = [&](const char *name) {  // RTCORE_DEBUG_TREE=1: where the build time goes
-        auto now = std::chrono::steady_clock::now();
-        if (debug_tree) std::fprintf(stderr, "[rtcore] build: %-28s %.3f s\n", name, std::chrono::duration<double>(now - t_phase).count());
-        t_phase = now;
-    };
+// Validates a scene description and counts its primitives (one per object, one per face of a mesh object).
+int check_scene_desc(const RtSceneDesc *d, uint64_t &total_out, std::string &err, bool check_indices) {
     if (!d || (d->n_objects && !d->objects) || (d->n_materials && !d->materials) || (d->n_meshes && !d->meshes)) {
         err = "null scene description";
         return RT_ERR_INVALID_ARGUMENT;
@@ -731,7 +725,7 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
                 err = "object " + std::to_string(i) + ": mesh needs positions, normals and indices";
                 return RT_ERR_INVALID_ARGUMENT;
             }
-            for (uint64_t k = 0; k < 3 * m.n_faces; k++)
+            for (uint64_t k = 0; check_indices && k < 3 * m.n_faces; k++)
                 if (m.indices[k] >= m.n_vertices) {
                     err = "object " + std::to_string(i) + ": vertex index out of range";
                     return RT_ERR_INVALID_ARGUMENT;
@@ -751,6 +745,100 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
     if (d->n_materials >= (1u << 28)) {
         err = "too many materials";
         return RT_ERR_INVALID_ARGUMENT;
+    }
+
+    total_out = total;
+    return RT_OK;
+}
+
+// The record, the normals word block and the bounding box of a scene object that is ONE primitive (sphere, axis box,
+// rotated box, triangle): rec[12] words, nrm[12] floats (three vertex normals, 4 floats apart; zero for non-triangles),
+// box = lo[3], hi[3].  `id` is the primitive id (declaration order).  Mesh faces are made by triangle_record.
+void triangle_record(const float vv[9], const float nn[9], bool two_sided, uint32_t mat_bits, uint32_t id, uint32_t *rec,
+                     float *nrm, float *box) {
+    for (int k = 0; k < 3; k++) {
+        rec[k] = fbits(vv[k]);
+        rec[3 + k] = fbits(vv[3 + k] - vv[k]);
+        rec[6 + k] = fbits(vv[6 + k] - vv[k]);
+    }
+    rec[9] = 0;
+    rec[10] = RT_PRIM_TRIANGLE | (two_sided ? RT_PRIM_FLAG : 0) | mat_bits;
+    rec[11] = id;
+    for (int k = 0; k < 3; k++) nrm[4 * k] = nn[3 * k], nrm[4 * k + 1] = nn[3 * k + 1], nrm[4 * k + 2] = nn[3 * k + 2], nrm[4 * k + 3] = 0.0f;
+    for (int a = 0; a < 3; a++) {  // Triangle::bounding_box (src/tracer/triangle.rs:80-105)
+        box[a] = fmin_(vv[a], fmin_(vv[3 + a], vv[6 + a]));
+        box[3 + a] = fmax_(vv[a], fmax_(vv[3 + a], vv[6 + a]));
+    }
+}
+
+void simple_object_record(const RtObject &o, uint32_t id, uint32_t *rec, float *nrm, float *box) {
+    const uint32_t mat = (uint32_t)o.material << RT_PRIM_MAT_SHIFT;
+    for (int k = 0; k < 12; k++) rec[k] = 0, nrm[k] = 0.0f;
+    rec[11] = id;
+    switch (o.type) {
+        case RT_OBJ_SPHERE: {
+            for (int k = 0; k < 3; k++) rec[k] = fbits(o.a[k]);
+            rec[3] = fbits(o.b[0]);
+            rec[10] = RT_PRIM_SPHERE | mat;
+            float r = 1.0f * std::fabs(o.b[0]);  // Sphere::bounding_box (src/tracer/sphere.rs:60-65)
+            for (int k = 0; k < 3; k++) box[k] = o.a[k] - r, box[3 + k] = o.a[k] + r;
+            break;
+        }
+        case RT_OBJ_ABOX:
+        case RT_OBJ_CUBE: {
+            // ABox::new (src/tracer/cube.rs:20-38)
+            bool hollow = fmin_(fmin_(o.b[0], o.b[1]), o.b[2]) < 0.0f;
+            float half[3], lo[3], hi[3];
+            for (int k = 0; k < 3; k++) {
+                half[k] = std::fabs(o.b[k] * 0.5f);
+                lo[k] = o.a[k] - half[k];
+                hi[k] = o.a[k] + half[k];
+            }
+            if (o.type == RT_OBJ_ABOX) {
+                for (int k = 0; k < 3; k++) rec[k] = fbits(lo[k]), rec[3 + k] = fbits(hi[k]);
+                rec[10] = RT_PRIM_ABOX | (hollow ? RT_PRIM_FLAG : 0) | mat;
+                for (int k = 0; k < 3; k++) box[k] = lo[k], box[3 + k] = hi[k];
+            } else {
+                // Cube::new / Cube::bounding_box (src/tracer/cube.rs:90-102, :120-148)
+                Rotor rot = rotor_from_euler(o.c[2] * kPi, o.c[0] * kPi, o.c[1] * kPi);
+                for (int k = 0; k < 3; k++) rec[k] = fbits(o.a[k]), rec[3 + k] = fbits(half[k]);
+                rec[6] = fbits(rot.s), rec[7] = fbits(rot.xy), rec[8] = fbits(rot.xz), rec[9] = fbits(rot.yz);
+                rec[10] = RT_PRIM_CUBE | (hollow ? RT_PRIM_FLAG : 0) | mat;
+                V3 c = v3(o.a[0], o.a[1], o.a[2]);
+                for (int k = 0; k < 3; k++) box[k] = INFINITY, box[3 + k] = -INFINITY;
+                for (int corner = 0; corner < 8; corner++) {
+                    V3 p = v3((corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]);
+                    V3 q = add(rotate(rot, sub(p, c)), c);
+                    box[0] = fmin_(box[0], q.x), box[1] = fmin_(box[1], q.y), box[2] = fmin_(box[2], q.z);
+                    box[3] = fmax_(box[3], q.x), box[4] = fmax_(box[4], q.y), box[5] = fmax_(box[5], q.z);
+                }
+            }
+            break;
+        }
+        default:  // RT_OBJ_TRIANGLE
+            triangle_record(o.tri_vertices, o.tri_normals, o.flag != 0, mat, id, rec, nrm, box);
+            break;
+    }
+}
+
+// The rotor of Mesh::new (src/tracer/mesh.rs:31): rotation in radians, from_euler_angles(z, x, y), normalised.
+void mesh_rotor(const RtMesh &m, float rot[4]) {
+    Rotor r = rotor_from_euler(m.rotation[2], m.rotation[0], m.rotation[1]);
+    rot[0] = r.s, rot[1] = r.xy, rot[2] = r.xz, rot[3] = r.yz;
+}
+
+int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
+    const bool debug_tree = std::getenv("RTCORE_DEBUG_TREE") != nullptr;
+    auto t_phase = std::chrono::steady_clock::now();
+    auto phase = [&](const char *name) {  // RTCORE_DEBUG_TREE=1: where the build time goes
+        auto now = std::chrono::steady_clock::now();
+        if (debug_tree) std::fprintf(stderr, "[rtcore] build: %-28s %.3f s\n", name, std::chrono::duration<double>(now - t_phase).count());
+        t_phase = now;
+    };
+    uint64_t total = 0;
+    {
+        int rc = check_scene_desc(d, total, err);
+        if (rc) return rc;
     }
 
     phase("checks");
@@ -787,64 +875,15 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
             b.lo[2] = fmin_(vv[0].z, fmin_(vv[1].z, vv[2].z)), b.hi[2] = fmax_(vv[0].z, fmax_(vv[1].z, vv[2].z));
         };
         switch (o.type) {
-            case RT_OBJ_SPHERE: {
-                put3(id, 0, v3(o.a[0], o.a[1], o.a[2]));
-                rec[id * 12 + 3] = fbits(o.b[0]);
-                rec[id * 12 + 10] = RT_PRIM_SPHERE | mat;
-                rec[id * 12 + 11] = (uint32_t)id;
-                float r = 1.0f * std::fabs(o.b[0]);  // Sphere::bounding_box (src/tracer/sphere.rs:60-65)
-                for (int k = 0; k < 3; k++) boxes[id].lo[k] = o.a[k] - r, boxes[id].hi[k] = o.a[k] + r;
-                world_items.push_back(Item{~(int32_t)id, boxes[id]});
-                id++;
-                break;
-            }
+            case RT_OBJ_SPHERE:
             case RT_OBJ_ABOX:
-            case RT_OBJ_CUBE: {
-                // ABox::new (src/tracer/cube.rs:20-38)
-                bool hollow = fmin_(fmin_(o.b[0], o.b[1]), o.b[2]) < 0.0f;
-                float half[3], lo[3], hi[3];
-                for (int k = 0; k < 3; k++) {
-                    half[k] = std::fabs(o.b[k] * 0.5f);
-                    lo[k] = o.a[k] - half[k];
-                    hi[k] = o.a[k] + half[k];
-                }
-                if (o.type == RT_OBJ_ABOX) {
-                    put3(id, 0, v3(lo[0], lo[1], lo[2]));
-                    put3(id, 3, v3(hi[0], hi[1], hi[2]));
-                    rec[id * 12 + 10] = RT_PRIM_ABOX | (hollow ? RT_PRIM_FLAG : 0) | mat;
-                    for (int k = 0; k < 3; k++) boxes[id].lo[k] = lo[k], boxes[id].hi[k] = hi[k];
-                } else {
-                    // Cube::new / Cube::bounding_box (src/tracer/cube.rs:90-102, :120-148)
-                    Rotor rot = rotor_from_euler(o.c[2] * kPi, o.c[0] * kPi, o.c[1] * kPi);
-                    put3(id, 0, v3(o.a[0], o.a[1], o.a[2]));
-                    put3(id, 3, v3(half[0], half[1], half[2]));
-                    rec[id * 12 + 6] = fbits(rot.s), rec[id * 12 + 7] = fbits(rot.xy);
-                    rec[id * 12 + 8] = fbits(rot.xz), rec[id * 12 + 9] = fbits(rot.yz);
-                    rec[id * 12 + 10] = RT_PRIM_CUBE | (hollow ? RT_PRIM_FLAG : 0) | mat;
-                    V3 c = v3(o.a[0], o.a[1], o.a[2]);
-                    Box &b = boxes[id];
-                    for (int k = 0; k < 3; k++) b.lo[k] = INFINITY, b.hi[k] = -INFINITY;
-                    for (int corner = 0; corner < 8; corner++) {
-                        V3 p = v3((corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]);
-                        V3 q = add(rotate(rot, sub(p, c)), c);
-                        b.lo[0] = fmin_(b.lo[0], q.x), b.lo[1] = fmin_(b.lo[1], q.y), b.lo[2] = fmin_(b.lo[2], q.z);
-                        b.hi[0] = fmax_(b.hi[0], q.x), b.hi[1] = fmax_(b.hi[1], q.y), b.hi[2] = fmax_(b.hi[2], q.z);
-                    }
-                }
-                rec[id * 12 + 11] = (uint32_t)id;
-                world_items.push_back(Item{~(int32_t)id, boxes[id]});
-                id++;
-                break;
-            }
+            case RT_OBJ_CUBE:
             case RT_OBJ_TRIANGLE: {
-                V3 vv[3], nn[3];
-                for (int k = 0; k < 3; k++) {
-                    vv[k] = v3(o.tri_vertices[3 * k], o.tri_vertices[3 * k + 1], o.tri_vertices[3 * k + 2]);
-                    nn[k] = v3(o.tri_normals[3 * k], o.tri_normals[3 * k + 1], o.tri_normals[3 * k + 2]);
-                }
-                tri(id, vv, nn, o.flag != 0);
+                float bx[6];
+                simple_object_record(o, (uint32_t)id, &rec[id * 12], &nrm[id * 12], bx);
+                for (int k = 0; k < 3; k++) boxes[id].lo[k] = bx[k], boxes[id].hi[k] = bx[3 + k];
                 world_items.push_back(Item{~(int32_t)id, boxes[id]});
-                hs.n_triangles++;
+                if (o.type == RT_OBJ_TRIANGLE) hs.n_triangles++;
                 id++;
                 break;
             }
@@ -1031,6 +1070,11 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
     phase("records in rank order");
     hs.n_prims = total;
 
+    return fill_materials_camera_env(d, hs, err);
+}
+
+// Materials, camera and environment of a scene description (everything of a HostScene that is not the tree).
+int fill_materials_camera_env(const RtSceneDesc *d, HostScene &hs, std::string &err) {
     hs.materials.resize(d->n_materials);
     for (uint64_t i = 0; i < d->n_materials; i++) {
         const RtMaterial &m = d->materials[i];

@@ -29,6 +29,13 @@ struct HostScene {
 // Returns RT_OK or a negative RtStatus and fills `err`.
 int build_host_scene(const RtSceneDesc *desc, HostScene &out, std::string &err);
 
+// Pieces of the build that the device-side builder shares with it (same arithmetic, hence the same records).
+// (check_indices = false leaves the vertex indices of the meshes unchecked: the device build checks them itself)
+int check_scene_desc(const RtSceneDesc *desc, uint64_t &n_primitives, std::string &err, bool check_indices = true);
+int fill_materials_camera_env(const RtSceneDesc *desc, HostScene &out, std::string &err);
+void simple_object_record(const RtObject &o, uint32_t id, uint32_t *rec12, float *nrm12, float *box6);
+void mesh_rotor(const RtMesh &m, float rot[4]);
+
 // Camera::new (src/camera.rs:21-50)
 void make_camera(const RtCamera &c, float aspect, RtDevCamera &out);
 

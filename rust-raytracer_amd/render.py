@@ -32,12 +32,14 @@ def _ptr(a):
 class Scene:
     """An immutable world on the current HIP device (the reference's Arc<Bvh> plus environment and camera)."""
 
-    def __init__(self, description):
+    def __init__(self, description, builder=_abi.RT_BUILD_DEFAULT):
+        """builder: RT_BUILD_EXACT (the reference's tree, built on the host), RT_BUILD_DEVICE (built on the GPU) or
+        RT_BUILD_DEFAULT (the environment's RTCORE_BUILD decides, exact otherwise)."""
         self._lib = _abi.load()
         self._desc_owner = description
         desc = description.to_desc()
         handle = C.c_void_p()
-        _abi.check(self._lib.rt_scene_create(C.byref(desc), C.byref(handle)))
+        _abi.check(self._lib.rt_scene_create_with(C.byref(desc), int(builder), C.byref(handle)))
         self._h = handle
 
     def close(self):
