@@ -45,6 +45,7 @@ from srchash import kernel_source_hash  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
 N_SIMD = 1024          # 256 CUs x 4
+N_CU = 256
 MAX_CLOCK_GHZ = 2.4
 
 
@@ -218,6 +219,7 @@ def main():
     visits_per_ray = cs.node_visits / max(1, cs.rays)
     tests_per_ray = cs.prim_tests / max(1, cs.rays)
     bytes_per_ray = visits_per_ray * info.node_bytes + tests_per_ray * info.primitive_bytes + 32 + 8
+    lookups_per_ray = cs.l1_lookups / max(1, cs.rays)
     steps_counted = cs.node_steps + cs.leaf_steps
     step_lane_occupancy = ((cs.node_step_lanes + cs.leaf_step_lanes) / (64.0 * steps_counted)) if steps_counted else None
 
@@ -289,6 +291,16 @@ def main():
             "node_visits_per_ray": round(visits_per_ray, 2),
             "prim_tests_per_ray": round(tests_per_ray, 2),
         }
+        if extend_s > 0 and lookups_per_ray > 0:
+            # The vector L1 looks up one 128-byte line per clock and CU (tools/ubench/node_fetch.hip: 7 loads per lane
+            # from a line of its own, L2-resident table: 6.5 clocks per node and CU), and a wave's load instruction
+            # costs one look-up per DIFFERENT line among its lanes.  Look-ups of the node and primitive fetches are
+            # counted live by the instrumented kernel; ray loads, hit stores and stack overflow are not included.
+            peak = N_CU * MAX_CLOCK_GHZ
+            achieved = st.rays * lookups_per_ray / extend_s / 1e9
+            roof["l1_lookup"] = {"achieved_G_per_s": round(achieved, 1), "peak_G_per_s": round(peak, 1),
+                                 "frac": round(achieved / peak, 4), "lookups_per_ray": round(lookups_per_ray, 1),
+                                 "note": "one line look-up per clock and CU; counted for node and primitive fetches only"}
         if prof is not None:
             e = prof["extend"]
             clock = e.get("clock_GHz_under_profile") or MAX_CLOCK_GHZ

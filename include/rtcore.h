@@ -217,6 +217,9 @@ typedef struct RtStats {
     uint64_t node_step_lanes;
     uint64_t leaf_steps;
     uint64_t leaf_step_lanes;
+    /* Line look-ups the node and primitive fetches of the closest-hit kernel ask of the vector L1 (one per load
+     * instruction and different 128-byte line among its lanes); only filled by the counting kernel. */
+    uint64_t l1_lookups;
 } RtStats;
 
 /* Library / device bring-up.  device < 0 keeps the current HIP device. */

@@ -137,6 +137,7 @@ class RtStats(C.Structure):
         ("node_step_lanes", C.c_uint64),
         ("leaf_steps", C.c_uint64),
         ("leaf_step_lanes", C.c_uint64),
+        ("l1_lookups", C.c_uint64),
     ]
 
 

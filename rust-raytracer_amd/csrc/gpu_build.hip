@@ -483,7 +483,7 @@ __global__ void __launch_bounds__(kBlock) collapse_kernel(const uint32_t *queue_
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) bx[a][i] = 0.0f;
+        for (int i = 0; i < 4; i++) bx[a][i] = __int_as_float(0x7f800000);  // an empty slot: a box no ray hits
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         if (i >= n_slots) continue;
@@ -515,8 +515,9 @@ __global__ void tiny_tree_kernel(int n, const float4 *leaf_lo, const float4 *lea
         hi = make_float4(fmax_(hi.x, h1.x) + kEps, fmax_(hi.y, h1.y) + kEps, fmax_(hi.z, h1.z) + kEps, 0.0f);
     }
     node_lo[0] = lo, node_hi[0] = hi;
-    wide[0] = make_float4(lo.x, 0, 0, 0), wide[1] = make_float4(lo.y, 0, 0, 0), wide[2] = make_float4(lo.z, 0, 0, 0);
-    wide[3] = make_float4(hi.x, 0, 0, 0), wide[4] = make_float4(hi.y, 0, 0, 0), wide[5] = make_float4(hi.z, 0, 0, 0);
+    const float e = __int_as_float(0x7f800000);  // the empty slots: boxes no ray hits
+    wide[0] = make_float4(lo.x, e, e, e), wide[1] = make_float4(lo.y, e, e, e), wide[2] = make_float4(lo.z, e, e, e);
+    wide[3] = make_float4(hi.x, e, e, e), wide[4] = make_float4(hi.y, e, e, e), wide[5] = make_float4(hi.z, e, e, e);
     wide[6] = make_float4(__uint_as_float(RT_CHILD_LEAF | ((uint32_t)(n - 1) << 28)), __uint_as_float(RT_CHILD_NONE),
                           __uint_as_float(RT_CHILD_NONE), __uint_as_float(RT_CHILD_NONE));
     wide[7] = make_float4(0, 0, 0, 0);

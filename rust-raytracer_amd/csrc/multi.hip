@@ -342,6 +342,8 @@ int rt_multi_gpu_stats(RtMulti *m, RtStats *total) {
         total->rays += st.rays, total->paths += st.paths, total->node_visits += st.node_visits, total->prim_tests += st.prim_tests;
         total->extend_ms += st.extend_ms, total->shade_ms += st.shade_ms, total->other_ms += st.other_ms;
         total->extend_launches += st.extend_launches;
+        total->node_steps += st.node_steps, total->node_step_lanes += st.node_step_lanes;
+        total->leaf_steps += st.leaf_steps, total->leaf_step_lanes += st.leaf_step_lanes, total->l1_lookups += st.l1_lookups;
     }
     (void)hipSetDevice(before);
     return RT_OK;

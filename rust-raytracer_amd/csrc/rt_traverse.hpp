@@ -240,8 +240,10 @@ RT_DEV bool traversal_begin(const RtSceneView &sc, Traversal &tr, Stack &st, flo
     // reference (NaN-ignoring min/max leave t_min <= t_max) and fails every primitive test, so it
     // would walk the whole tree only to miss.  Ray::new turns a zero or NaN direction into such a
     // ray.  The result is known without the walk.
-    if ((ray.d.x != ray.d.x && ray.d.y != ray.d.y && ray.d.z != ray.d.z) ||
-        (ray.o.x != ray.o.x && ray.o.y != ray.o.y && ray.o.z != ray.o.z))
+    // The same holds when every axis has a NaN in its origin or its direction component: every box test ignores
+    // every axis, and every primitive test mixes the components and fails.
+    if ((ray.d.x != ray.d.x || ray.o.x != ray.o.x) && (ray.d.y != ray.d.y || ray.o.y != ray.o.y) &&
+        (ray.d.z != ray.d.z || ray.o.z != ray.o.z))
         return false;
     tr.inv = f3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     // the root's own box (src/tracer/bvh.rs:144-147)
@@ -361,40 +363,105 @@ RT_DEV int node_children(const float4 nx4, const float4 ny4, const float4 nz4, c
     return (int)(key[0] < kInf) + (int)(key[1] < kInf) + (int)(key[2] < kInf) + (int)(key[3] < kInf);
 }
 
-// tr.entry is a node: tests its four child boxes, pushes the far hits and continues with the
+// The same slab tests for the lane-bound kernel's node step.  Out: the four (entry distance, child word) pairs sorted
+// ascending with the children that are NOT hit first (their key is -inf), so the hit children are the last nh pairs,
+// nearest first among them.  Straight-line code: the lanes of a wave hit different children, so a branch per
+// exchange would be taken by every wave anyway and only adds the moves of both sides.
+// An empty slot needs no test of its own: the builders give it a box at +infinity, which no ray that gets this far
+// hits (every axis of such a ray is either ignored -- a NaN in its origin or direction -- or gives +-inf on both
+// planes, and traversal_begin answers the rays whose three axes are all ignored).
+RT_DEV int node_children_sorted(const float4 nx4, const float4 ny4, const float4 nz4, const float4 fx4, const float4 fy4,
+                                const float4 fz4, const float4 cwf, const F3 o, const F3 inv, float t_min, float t_best,
+                                float key[4], uint32_t cw[4]) {
+    cw[0] = __float_as_uint(cwf.x), cw[1] = __float_as_uint(cwf.y), cw[2] = __float_as_uint(cwf.z), cw[3] = __float_as_uint(cwf.w);
+    typedef float Pair __attribute__((ext_vector_type(2)));
+    const Pair ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const Pair ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const Pair t0x[2] = {(Pair{nx4.x, nx4.y} - ox) * ix, (Pair{nx4.z, nx4.w} - ox) * ix};
+    const Pair t1x[2] = {(Pair{fx4.x, fx4.y} - ox) * ix, (Pair{fx4.z, fx4.w} - ox) * ix};
+    const Pair t0y[2] = {(Pair{ny4.x, ny4.y} - oy) * iy, (Pair{ny4.z, ny4.w} - oy) * iy};
+    const Pair t1y[2] = {(Pair{fy4.x, fy4.y} - oy) * iy, (Pair{fy4.z, fy4.w} - oy) * iy};
+    const Pair t0z[2] = {(Pair{nz4.x, nz4.y} - oz) * iz, (Pair{nz4.z, nz4.w} - oz) * iz};
+    const Pair t1z[2] = {(Pair{fz4.x, fz4.y} - oz) * iz, (Pair{fz4.z, fz4.w} - oz) * iz};
+    const float kNegInf = __int_as_float(0xff800000);
+    int nh = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float ax0 = t0x[c >> 1][c & 1], ax1 = t1x[c >> 1][c & 1];
+        const float ay0 = t0y[c >> 1][c & 1], ay1 = t1y[c >> 1][c & 1];
+        const float az0 = t0z[c >> 1][c & 1], az1 = t1z[c >> 1][c & 1];
+        float nxv = fminf(ax0, ax1), fxv = fmaxf(ax0, ax1);
+        float nyv = fminf(ay0, ay1), fyv = fmaxf(ay0, ay1);
+        float nzv = fminf(az0, az1), fzv = fmaxf(az0, az1);
+        float tn = fmaxf(fmaxf(fmaxf(nxv, nyv), nzv), t_min);
+        float tf = fminf(fminf(fminf(fxv, fyv), fzv), t_best);
+        const bool hit = tn <= tf;
+        key[c] = hit ? tn : kNegInf;
+        nh += hit ? 1 : 0;
+    }
+#define RT_CSEL(i, j)                                   \
+    {                                                   \
+        const bool sw = key[j] < key[i];                \
+        const float ki = sw ? key[j] : key[i];          \
+        const float kj = sw ? key[i] : key[j];          \
+        const uint32_t wi = sw ? cw[j] : cw[i];         \
+        const uint32_t wj = sw ? cw[i] : cw[j];         \
+        key[i] = ki, key[j] = kj, cw[i] = wi, cw[j] = wj; \
+    }
+    RT_CSEL(0, 1) RT_CSEL(2, 3) RT_CSEL(0, 2) RT_CSEL(1, 3) RT_CSEL(1, 2)
+#undef RT_CSEL
+    return nh;
+}
+
+// The seven 16-byte words of a wide node.
+struct NodeWords {
+    float4 nx4, ny4, nz4, fx4, fy4, fz4, cwf;
+};
+
+// A lane fetches its own node: seven 16-byte loads from one 128-byte line.
+RT_DEV void node_fetch_own(const RtSceneView &sc, uint32_t entry, NodeWords &w) {
+    const char *__restrict__ nodes = (const char *)sc.nodes;
+    const uint32_t base = entry * (RT_NODE_FLOAT4S * 16u);  // 32-bit byte offsets from the (uniform) node array base
+    w.nx4 = *(const float4 *)(nodes + (base + 0u));
+    w.ny4 = *(const float4 *)(nodes + (base + 16u));
+    w.nz4 = *(const float4 *)(nodes + (base + 32u));
+    w.fx4 = *(const float4 *)(nodes + (base + 48u));
+    w.fy4 = *(const float4 *)(nodes + (base + 64u));
+    w.fz4 = *(const float4 *)(nodes + (base + 80u));
+    w.cwf = *(const float4 *)(nodes + (base + 96u));
+}
+
+// tr.entry is a node whose words are `w`: tests its four child boxes, pushes the far hits and continues with the
 // nearest.  Returns true when no child was hit: the lane then wants the next stack entry.
 template <bool COUNT>
-RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
-    const char *__restrict__ nodes = (const char *)sc.nodes;
-    // 32-bit byte offsets from the (uniform) node array base
-    const uint32_t base = tr.entry * (RT_NODE_FLOAT4S * 16u);
-    const float4 nx4 = *(const float4 *)(nodes + (base + 0u));
-    const float4 ny4 = *(const float4 *)(nodes + (base + 16u));
-    const float4 nz4 = *(const float4 *)(nodes + (base + 32u));
-    const float4 fx4 = *(const float4 *)(nodes + (base + 48u));
-    const float4 fy4 = *(const float4 *)(nodes + (base + 64u));
-    const float4 fz4 = *(const float4 *)(nodes + (base + 80u));
-    const float4 cwf = *(const float4 *)(nodes + (base + 96u));
+RT_DEV bool traversal_node_process(const NodeWords &w, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
     if (COUNT) (*visits)++;
     float key[4];
     uint32_t cw[4];
-    // hits are key[0 .. nh); the nearest continues, the others go on the stack far to near
-    const int nh = node_children(nx4, ny4, nz4, fx4, fy4, fz4, cwf, tr.ray.o, tr.inv, t_min, tr.best.t, key, cw);
-    if (nh > 1) {
-        const int top = st.sp + nh - 1;
-        if (top <= RT_LDS_STACK) {
-            if (nh > 1) st.lds[(top - 1) * st.lds_stride] = make_uint2(cw[1], __float_as_uint(key[1]));
-            if (nh > 2) st.lds[(top - 2) * st.lds_stride] = make_uint2(cw[2], __float_as_uint(key[2]));
-            if (nh > 3) st.lds[(top - 3) * st.lds_stride] = make_uint2(cw[3], __float_as_uint(key[3]));
-        } else {
-            if (nh > 1) st.store(top - 1, cw[1], key[1]);
-            if (nh > 2) st.store(top - 2, cw[2], key[2]);
-            if (nh > 3) st.store(top - 3, cw[3], key[3]);
-        }
-        st.sp = top;
+    // the hit children are the pairs [4 - nh, 4), nearest first
+    const int nh = node_children_sorted(w.nx4, w.ny4, w.nz4, w.fx4, w.fy4, w.fz4, w.cwf, tr.ray.o, tr.inv, t_min, tr.best.t, key, cw);
+    // The farthest goes to the stack first, the nearest continues.  Pairs 3, 2, 1 are written to the three entries above
+    // the top whether they are hit children or not: what is not one lies above the new top, where nothing reads it.
+    if (st.sp + 3 <= RT_LDS_STACK) {
+        uint2 *top = st.lds + st.sp * st.lds_stride;
+        top[0] = make_uint2(cw[3], __float_as_uint(key[3]));
+        top[st.lds_stride] = make_uint2(cw[2], __float_as_uint(key[2]));
+        top[2 * st.lds_stride] = make_uint2(cw[1], __float_as_uint(key[1]));
+    } else {
+        if (nh > 1) st.store(st.sp, cw[3], key[3]);
+        if (nh > 2) st.store(st.sp + 1, cw[2], key[2]);
+        if (nh > 3) st.store(st.sp + 2, cw[1], key[1]);
     }
-    if (nh > 0) tr.entry = cw[0];
+    st.sp += nh > 1 ? nh - 1 : 0;
+    tr.entry = nh == 1 ? cw[3] : (nh == 2 ? cw[2] : (nh == 3 ? cw[1] : cw[0]));
     return nh == 0;
+}
+
+template <bool COUNT>
+RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
+    NodeWords w;
+    node_fetch_own(sc, tr.entry, w);
+    return traversal_node_process<COUNT>(w, tr, st, t_min, visits);
 }
 
 }  // namespace rtd

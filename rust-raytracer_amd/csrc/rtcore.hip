@@ -127,6 +127,18 @@ constexpr int kPopTurns = RT_POP_TURNS;
 constexpr uint32_t kRayChunk = RT_RAY_CHUNK;
 constexpr uint32_t kServiceLanes = RT_SERVICE_LANES;
 
+// Number of different values of `v` among the lanes with `on` (instrumented builds only: one turn per value).
+__device__ __forceinline__ uint32_t wave_distinct(bool on, uint32_t v) {
+    unsigned long long rest = __ballot(on);
+    uint32_t n = 0;
+    while (rest) {
+        const uint32_t leader = (uint32_t)__shfl((int)v, __ffsll((long long)rest) - 1, 64);
+        rest &= ~__ballot(on && v == leader);
+        n++;
+    }
+    return n;
+}
+
 template <bool COUNT>
 __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     extend_kernel(RtSceneView sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
@@ -142,6 +154,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     st.ovf_stride = gridDim.x * blockDim.x;
     st.sp = 0;
     uint32_t visits = 0, tests = 0;
+    unsigned long long lookups = 0;  // (wave-uniform) line look-ups of the node and primitive fetches
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // leaf steps, lanes in them, node steps, lanes in them, lanes without a ray over all steps, refills (lane 0 of each wave)
     Traversal tr;
     int32_t ray_i = -1;     // ray this lane works on, -1 = none
@@ -220,6 +233,19 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
             if (run_node && n_node) dbg[2]++, dbg[3] += n_node;
             dbg[4] += 64u - n_leaf - n_node;
         }
+        if (COUNT) {
+            // What the step asks of the vector L1: every load instruction looks up each DIFFERENT 128-byte line its
+            // lanes address (a node is seven loads from one line; a primitive record is three loads, 48 bytes that may
+            // straddle two lines).  Lanes at the same node or in the same line share a look-up.
+            uint32_t lk = 0;
+            if (run_node && n_node) lk += 7u * wave_distinct(at_node, tr.entry);
+            if (run_leaf && n_leaf) {
+                const uint32_t byte0 = (tr.entry & RT_LEAF_FIRST_MASK) * (RT_PRIM_FLOAT4S * 16u);
+                const bool two = ((tr.entry >> 28) & 7u) != 0u;
+                for (uint32_t k = 0; k < 6u; k++) lk += wave_distinct(at_leaf && (k < 3u || two), (byte0 + 16u * k) >> 7);
+            }
+            lookups += lk;
+        }
         if (run_leaf && at_leaf) {
             traversal_leaf_step<COUNT>(sc, tr, t_min, t_max, &tests);
             popping = true;
@@ -241,6 +267,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         {
             dbg[7] = (unsigned long long)(clock64() - loop_t0);
             for (int k = 0; k < 8; k++) atomicAdd(&counters[2 + k], dbg[k]);
+            atomicAdd(&counters[14], lookups);
         }
     }
 }
@@ -1141,6 +1168,7 @@ int rt_scene_stats(const RtScene *cs, RtStats *out) {
         s->stats.prim_tests += c[1];
         s->stats.leaf_steps += c[2], s->stats.leaf_step_lanes += c[3];
         s->stats.node_steps += c[4], s->stats.node_step_lanes += c[5];
+        s->stats.l1_lookups += c[14];
         if (std::getenv("RTCORE_DEBUG_STEPS") && c[2] + c[4])
             std::fprintf(stderr,
                          "[rtcore] leaf steps %llu with %.1f lanes, node steps %llu with %.1f lanes, %.1f lanes not stepping "

@@ -416,7 +416,7 @@ struct Collapser {
         uint32_t words[4] = {RT_CHILD_NONE, RT_CHILD_NONE, RT_CHILD_NONE, RT_CHILD_NONE};
         float boxes[6][4];
         for (int a = 0; a < 6; a++)
-            for (int i = 0; i < 4; i++) boxes[a][i] = 0.0f;
+            for (int i = 0; i < 4; i++) boxes[a][i] = INFINITY;  // an empty slot: a box no ray hits (see node_children_sorted)
         for (int i = 0; i < n; i++) {
             for (int a = 0; a < 3; a++) {
                 boxes[a][i] = slots[i].box.lo[a];
@@ -638,7 +638,9 @@ struct SahCollapser {
         size_t me = out.size() / 32;
         out.resize(out.size() + 32, 0.0f);
         uint32_t words[4] = {RT_CHILD_NONE, RT_CHILD_NONE, RT_CHILD_NONE, RT_CHILD_NONE};
-        float boxes[6][4] = {};
+        float boxes[6][4];
+        for (int a = 0; a < 6; a++)
+            for (int i = 0; i < 4; i++) boxes[a][i] = INFINITY;  // an empty slot: a box no ray hits
         for (int i = 0; i < n; i++) {
             const Box &b = sn[kids[i]].box;
             for (int a = 0; a < 3; a++) boxes[a][i] = b.lo[a], boxes[3 + a][i] = b.hi[a];
