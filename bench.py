@@ -11,18 +11,19 @@ Prints ONE JSON line on rank 0:
 
   value        Mrays/s of the whole job: Bvh::hit invocations (primary rays + every continued
                bounce) of all ranks / max-over-ranks wall time of the K steps
-  roofline     closest-hit ("extend") kernel.  The kernel is bound by vector-instruction issue under
-               divergence, not by bytes (its counters: VALU busy ~0.9 of SIMD cycles at about half the
-               lanes active), so the fraction reported is the USEFUL share of the vector unit:
-                 frac = (SIMD cycles issuing VALU / SIMD cycles) x (active lanes / 64 per VALU instruction)
-               from the rocprofv3 counter profile of this same configuration under profiles/, used
-               only while its stamp (hash of the kernel sources, bench arguments) matches this run;
-               otherwise frac falls back to the lane occupancy of the kernel's steps, counted live by
-               the instrumented kernel.  Beside it, reported and not used as the fraction:
-               the HBM side (FETCH_SIZE of the same profile x the factor calibrated on a one-line-per-
-               lane gather, / launch time, / 8 TB/s) and the algorithmic bytes per ray (node visits
-               x 128 B + primitive tests x 48 B + 40 B, counted live at the timed resolution), most of
-               which the caches serve.  Launch durations are HIP events on the launch stream.
+  roofline     closest-hit ("extend") kernel.  Its loads are per-lane 16-byte gathers (a tree node = seven loads from one
+               128-byte line per lane), and what they saturate is the CU's vector memory path: address unit (TA),
+               L1 tags (TCP) and data return (TD), which take one cache-line access per clock and CU.
+                 frac = TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles)          [bound "l1"]
+               from the rocprofv3 counter profile of this same configuration under profiles/, used only while its
+               stamp (hash of the kernel sources, bench arguments) matches this run; TA / TD busy fractions beside it.
+               Without a matching profile: the line look-ups of the node and primitive fetches, counted live by the
+               instrumented kernel (a lower bound of the accesses).  Also reported, not used as the fraction:
+               the vector ALU (VALU busy x active lanes / 64 per instruction: the unit is busy ~0.9 of the time at
+               about half its lanes), the HBM side (FETCH_SIZE x the factor calibrated on a one-line-per-lane gather,
+               / launch time, / 8 TB/s) and the algorithmic bytes per ray (node visits x 128 B + primitive tests x 48 B
+               + 40 B, counted live at the timed resolution), most of which the caches serve.  Launch durations are
+               HIP events on the launch stream.
   cpu_baseline the CPU oracle (a restatement of the reference's renderer, not the Rust binary)
                on a bounded sample of the same workload: same scene, samples and bounces at a
                reduced resolution, on this box's host cores (N=1 only)
@@ -273,9 +274,7 @@ def main():
         key = config_key(args)
         prof = matching_profile(key)
         roof = {
-            "bound": "valu",
             "kernel": "extend_kernel (closest hit)",
-            "unit": "G lane-op/s",
             "launches": launches,
             "mean_launch_ms": round(st.extend_ms / launches, 3),
             "extend_Mrays_per_s": round(st.rays / extend_s / 1e6, 1) if extend_s > 0 else None,
@@ -304,34 +303,56 @@ def main():
         if prof is not None:
             e = prof["extend"]
             clock = e.get("clock_GHz_under_profile") or MAX_CLOCK_GHZ
-            # G lane-op/s at one wave64 VALU instruction per 4 SIMD cycles on every SIMD: what "VALU busy = 1, all lanes active" is
-            peak = N_SIMD * 64 / 4.0 * clock
-            frac = e["valu_busy_fraction"] * e["valu_lane_utilisation"]
+            prof_launch_s = e["mean_launch_ms"] / 1e3
+            cu_cycles = prof_launch_s * clock * 1e9 * N_CU  # CU-cycles of one launch
+            # vector ALU: G lane-op/s at one wave64 instruction per 4 SIMD cycles on every SIMD ("VALU busy = 1, all lanes active")
+            valu_peak = N_SIMD * 64 / 4.0 * clock
+            valu_frac = e["valu_busy_fraction"] * e["valu_lane_utilisation"]
             factor, factor_note = fetch_factor()
             hbm_bytes = e["hbm_bytes_per_launch_raw"] * factor
-            prof_launch_s = e["mean_launch_ms"] / 1e3
-            roof.update({
-                "achieved": round(frac * peak, 1), "peak": round(peak, 1), "frac": round(frac, 4),
-                "valu_busy": round(e["valu_busy_fraction"], 4), "valu_lane_utilisation": round(e["valu_lane_utilisation"], 4),
-                "salu_per_valu_inst": round(e["SQ_INSTS_SALU_per_launch"] / e["SQ_INSTS_VALU_per_launch"], 3),
-                "traffic": int(hbm_bytes),
-                "hbm": {"achieved_GBps": round(hbm_bytes / prof_launch_s / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
-                        "frac": round(hbm_bytes / prof_launch_s / 1e9 / HBM_PEAK_GBS, 4),
-                        "fetch_size_raw_bytes": int(e["hbm_bytes_per_launch_raw"]), "factor": factor, "factor_note": factor_note,
-                        "l2_hit_rate": round(e.get("l2_hit_rate", 0.0), 4)},
-                "profile": {"file": prof["_file"], "source_hash": prof["source_hash"], "git_head": prof.get("git_head", ""),
-                            "mean_launch_ms_under_profile": round(e["mean_launch_ms"], 3),
-                            "note": "counters from separate rocprofv3 --pmc runs of this configuration (one run per counter group), "
-                                    "not from this run"},
-            })
+            valu = {"achieved_G_lane_op_per_s": round(valu_frac * valu_peak, 1), "peak_G_lane_op_per_s": round(valu_peak, 1),
+                    "frac": round(valu_frac, 4), "valu_busy": round(e["valu_busy_fraction"], 4),
+                    "valu_lane_utilisation": round(e["valu_lane_utilisation"], 4),
+                    "salu_per_valu_inst": round(e["SQ_INSTS_SALU_per_launch"] / e["SQ_INSTS_VALU_per_launch"], 3)}
+            hbm = {"achieved_GBps": round(hbm_bytes / prof_launch_s / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                   "frac": round(hbm_bytes / prof_launch_s / 1e9 / HBM_PEAK_GBS, 4),
+                   "fetch_size_raw_bytes": int(e["hbm_bytes_per_launch_raw"]), "factor": factor, "factor_note": factor_note,
+                   "l2_hit_rate": round(e.get("l2_hit_rate", 0.0), 4)}
+            roof.update({"traffic": int(hbm_bytes), "valu": valu, "hbm": hbm,
+                         "profile": {"file": prof["_file"], "source_hash": prof["source_hash"], "git_head": prof.get("git_head", ""),
+                                     "mean_launch_ms_under_profile": round(e["mean_launch_ms"], 3),
+                                     "note": "counters from separate rocprofv3 --pmc runs of this configuration (one run per counter group), "
+                                             "not from this run"}})
+            acc = e.get("TCP_TOTAL_CACHE_ACCESSES_sum_per_launch")
+            if acc:
+                # The kernel's loads are per-lane 16-byte gathers: what they load is the CU's vector memory path
+                # (address unit TA -> L1 tags TCP -> data return TD), which takes one cache-line access per clock.
+                peak = N_CU * clock
+                roof.update({"bound": "l1", "unit": "G line accesses/s",
+                             "achieved": round(acc / prof_launch_s / 1e9, 1), "peak": round(peak, 1),
+                             "frac": round(acc / cu_cycles, 4),
+                             "l1": {"accesses_per_launch": int(acc),
+                                    "ta_busy": round(e.get("TA_TA_BUSY_sum_per_launch", 0.0) / cu_cycles, 4),
+                                    "td_busy": round(e.get("TD_TD_BUSY_sum_per_launch", 0.0) / cu_cycles, 4),
+                                    "ta_stalled_by_l1": round(e.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum_per_launch", 0.0) / cu_cycles, 4),
+                                    "requests_to_l2_per_launch": int(e.get("TCP_TCC_READ_REQ_sum_per_launch", 0)),
+                                    "note": "TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles): one line access per clock and CU is what "
+                                            "tools/ubench/node_fetch.hip reaches with this load shape; TA / TD busy = the "
+                                            "address and data-return units' busy cycles / cycles"}})
+            else:
+                roof.update({"bound": "valu", "unit": "G lane-op/s", "achieved": valu["achieved_G_lane_op_per_s"],
+                             "peak": valu["peak_G_lane_op_per_s"], "frac": valu["frac"]})
         else:
-            # no counter profile of this code and configuration: the fraction of a wave's lanes the kernel's steps work for
-            roof.update({"achieved": None, "peak": round(N_SIMD * 64 / 4.0 * MAX_CLOCK_GHZ, 1),
-                         "frac": round(step_lane_occupancy, 4) if step_lane_occupancy is not None else None,
-                         "traffic": None,
+            # no counter profile of this code and configuration: the look-ups counted live by the instrumented kernel
+            # (node and primitive fetches only: a lower bound of the L1's accesses)
+            lk = roof.get("l1_lookup")
+            roof.update({"bound": "l1", "unit": "G line accesses/s",
+                         "achieved": lk["achieved_G_per_s"] if lk else None, "peak": round(N_CU * MAX_CLOCK_GHZ, 1),
+                         "frac": lk["frac"] if lk else None, "traffic": None,
                          "profile": {"file": None,
-                                     "note": "no profile under profiles/ matches source hash %s and configuration '%s'; frac is "
-                                             "the live step lane occupancy" % (kernel_source_hash(), key)}})
+                                     "note": "no profile under profiles/ matches source hash %s and configuration '%s'; achieved is "
+                                             "the live count of the node and primitive fetches' line look-ups, a lower bound of the "
+                                             "L1's accesses" % (kernel_source_hash(), key)}})
         out = {
             "metric": "Mrays/s (extend+shade)",
             "value": round(value, 2),

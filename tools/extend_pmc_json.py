@@ -59,7 +59,9 @@ def summarise(name):
         res["l2_hit_rate"] = sums["TCC_HIT_sum"] / (sums["TCC_HIT_sum"] + sums["TCC_MISS_sum"])
     for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
               "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT",
-              "TCC_REQ_sum", "TCC_READ_sum"):
+              "TCC_REQ_sum", "TCC_READ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_READ_sum",
+              "TCP_PENDING_STALL_CYCLES_sum", "TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TD_TD_BUSY_sum",
+              "TD_TC_STALL_sum"):
         if cnt.get(k):
             res[k + "_per_launch"] = sums[k] / cnt[k]
     return res

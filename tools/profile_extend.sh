@@ -20,6 +20,8 @@ pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD S
 pass sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT
 pass tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
 pass fetch FETCH_SIZE
+# the vector L1 and its address / data paths (cache line accesses, requests to L2, busy and stall cycles summed over the CUs)
+pass tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 find $OUT -type f ! -name "*.csv" ! -name "*.log" ! -name "*.txt" ! -name "*.json" -delete; find $OUT -name "*agent_info.csv" -delete
 python3 tools/extend_pmc_json.py $OUT gpurun_out/prof_$TAG.json > /dev/null && echo "summary in gpurun_out/prof_$TAG.json"
