@@ -230,8 +230,13 @@ def main():
     def reduce_sum(buf):
         if use_native:
             pkg.parallel.native_reduce(buf, rank, world, stream)
-        else:
+        elif backend == "nccl":
             dist.reduce(buf, dst=0)
+        else:
+            # rehearsal on another backend (gloo has no reduce for device tensors): through the host
+            host = buf.cpu()
+            dist.reduce(host, dst=0)
+            buf.copy_(host)
 
     if use_native:
         pkg.parallel.native_comm_init(rank, world, dist)
