@@ -212,12 +212,12 @@ struct Builder {
         while (mid < n - 1 && (it[mid].box.hi[axis] + it[mid].box.lo[axis]) * 0.5f <= mid_world) mid++;
         return mid;
     }
-    const Box &child_box(int32_t c, const std::vector<Box> &prim_boxes) const {
+    const Box &child_box(int32_t c, const RawVector<Box> &prim_boxes) const {
         return c >= 0 ? nodes[c].box : prim_boxes[~c];
     }
 
     // Bvh::new (src/tracer/bvh.rs:39-81)
-    int32_t build(Item *it, Scratch tmp, size_t n, const std::vector<Box> &prim_boxes, int depth) {
+    int32_t build(Item *it, Scratch tmp, size_t n, const RawVector<Box> &prim_boxes, int depth) {
         if (depth > 4096) {
             too_deep = true;
             return kNone;
@@ -260,18 +260,31 @@ struct Builder {
 
 struct Slot {
     Box box;
-    int32_t child;  // binary-tree child encoding
+    int32_t child;        // binary-tree child encoding
+    bool in_sub = false;  // the child lies in (or is the root of) one of the subtrees that are emitted on their own
+};
+
+// Where the wide nodes of one piece of the tree go.  The piece below the world's root is emitted first and leaves the
+// subtrees of the meshes to tasks that run side by side, each into an emitter of its own; the pieces are then put
+// one after the other and the node indices inside each piece moved by the piece's position.
+struct Emitter {
+    std::vector<float> out;  // 32 floats per wide node
+    uint32_t depth_max = 0;
+    bool overflow = false;
+    struct Deferred {
+        int32_t node;     // binary node that roots the wide node to emit
+        uint32_t depth;
+        size_t at;        // float index in `out` of the child word that names it
+    };
+    std::vector<Deferred> deferred;
 };
 
 struct Collapser {
     const std::vector<BNode> &bn;
     const std::vector<uint32_t> &rank_of;  // primitive -> visit rank
-    std::vector<float> &out;               // 32 floats per wide node
-    uint32_t depth_max = 0;
-    bool overflow = false;
+    std::vector<uint8_t> is_sub;           // per binary node: roots a subtree that is planned and emitted on its own
 
-    Collapser(const std::vector<BNode> &b, const std::vector<uint32_t> &r, std::vector<float> &o)
-        : bn(b), rank_of(r), out(o) {}
+    Collapser(const std::vector<BNode> &b, const std::vector<uint32_t> &r) : bn(b), rank_of(r) {}
 
     bool terminal(int32_t b) const {
         const BNode &n = bn[b];
@@ -291,8 +304,8 @@ struct Collapser {
         }
         return c;
     }
-    uint32_t leaf_word(uint32_t first, uint32_t count) {
-        if (first > RT_LEAF_FIRST_MASK || count == 0 || count > 2) overflow = true;  // the kernels fetch two records per leaf
+    static uint32_t leaf_word(Emitter &e, uint32_t first, uint32_t count) {
+        if (first > RT_LEAF_FIRST_MASK || count == 0 || count > 2) e.overflow = true;  // the kernels fetch two records per leaf
         return RT_CHILD_LEAF | ((count - 1) << 28) | first;
     }
 
@@ -315,17 +328,22 @@ struct Collapser {
         for (int j = 2; j <= k; j++) best = std::min(best, dist[j - 2][c]);
         return best;
     }
-    void plan(int32_t root) {
+    void plan_begin() {
         const size_t n = bn.size();
         root_cost.assign(n, 0.0f);
         for (int j = 0; j < 3; j++) dist[j].assign(n, 0.0f), to_left[j].assign(n, 1);
+        optimal = true;
+    }
+    // Fills the table for the subtree of `root`; subtrees marked in is_sub (other than root itself) are taken as done.
+    // Calls for disjoint subtrees may run side by side.
+    void plan(int32_t root) {
         std::vector<int32_t> order;
-        order.reserve(n);
         std::vector<int32_t> stack{root};
         while (!stack.empty()) {
             int32_t b = stack.back();
             stack.pop_back();
             if (terminal(b)) continue;
+            if (b != root && !is_sub.empty() && is_sub[b]) continue;
             order.push_back(b);
             if (bn[b].left != kNone && bn[b].left >= 0) stack.push_back(bn[b].left);
             if (bn[b].right != kNone && bn[b].right >= 0) stack.push_back(bn[b].right);
@@ -350,22 +368,22 @@ struct Collapser {
             }
             root_cost[b] = half_area(bn[b].box) + dist[2][b];
         }
-        optimal = true;
     }
     // the slots of the wide node that dissolves b into at most j slots, by the table
-    void gather(int32_t b, int j, Slot *slots, int &n) const {
+    void gather(int32_t b, int j, Slot *slots, int &n, bool in_sub) const {
         const int k = to_left[j - 2][b];
-        place(b, bn[b].left, k, slots, n);
-        place(b, bn[b].right, j - k, slots, n);
+        place(b, bn[b].left, k, slots, n, in_sub);
+        place(b, bn[b].right, j - k, slots, n, in_sub);
     }
-    void place(int32_t parent, int32_t c, int k, Slot *slots, int &n) const {
+    void place(int32_t parent, int32_t c, int k, Slot *slots, int &n, bool in_sub) const {
         if (c == kNone || k <= 0) return;
         if (c < 0) {
-            slots[n++] = Slot{bn[parent].box, c};  // a bare leaf is tested under its parent's box
+            slots[n++] = Slot{bn[parent].box, c, in_sub};  // a bare leaf is tested under its parent's box
             return;
         }
+        if (!is_sub.empty() && is_sub[c]) in_sub = true;
         if (terminal(c)) {
-            slots[n++] = Slot{bn[c].box, c};
+            slots[n++] = Slot{bn[c].box, c, in_sub};
             return;
         }
         float best = root_cost[c];
@@ -373,13 +391,15 @@ struct Collapser {
         for (int j = 2; j <= k; j++)
             if (dist[j - 2][c] < best) best = dist[j - 2][c], best_j = j;
         if (best_j == 1)
-            slots[n++] = Slot{bn[c].box, c};
+            slots[n++] = Slot{bn[c].box, c, in_sub};
         else
-            gather(c, best_j, slots, n);
+            gather(c, best_j, slots, n, in_sub);
     }
 
-    uint32_t make(int32_t b, uint32_t depth) {
-        if (depth > depth_max) depth_max = depth;
+    // Emits the wide node rooted at binary node b and everything below it into `e`; returns its index in e.out.
+    // With `defer`, wide nodes that lie in one of the is_sub subtrees are not emitted but noted in e.deferred.
+    uint32_t make(Emitter &e, int32_t b, uint32_t depth, bool defer) const {
+        if (depth > e.depth_max) e.depth_max = depth;
         Slot slots[4];
         int n;
         if (terminal(b)) {
@@ -387,7 +407,7 @@ struct Collapser {
             n = 1;
         } else if (optimal) {
             n = 0;
-            gather(b, 4, slots, n);
+            gather(b, 4, slots, n, false);
         } else {
             n = child_slots(b, slots);
             for (;;) {
@@ -411,8 +431,8 @@ struct Collapser {
                 if (k > 1) slots[n++] = kids[1];
             }
         }
-        size_t me = out.size() / 32;
-        out.resize(out.size() + 32, 0.0f);
+        const size_t me = e.out.size() / 32;
+        e.out.resize(e.out.size() + 32, 0.0f);
         uint32_t words[4] = {RT_CHILD_NONE, RT_CHILD_NONE, RT_CHILD_NONE, RT_CHILD_NONE};
         float boxes[6][4];
         for (int a = 0; a < 6; a++)
@@ -424,22 +444,25 @@ struct Collapser {
             }
             int32_t c = slots[i].child;
             if (c < 0) {
-                words[i] = leaf_word(rank_of[~c], 1);
+                words[i] = leaf_word(e, rank_of[~c], 1);
             } else if (terminal(c)) {
                 const BNode &t = bn[c];
                 // right is visited first, so it has the lower rank
                 if (t.left != kNone && t.right != kNone) {
                     uint32_t r0 = rank_of[~t.right], r1 = rank_of[~t.left];
-                    if (r1 != r0 + 1) overflow = true;
-                    words[i] = leaf_word(r0, 2);
+                    if (r1 != r0 + 1) e.overflow = true;
+                    words[i] = leaf_word(e, r0, 2);
                 } else {
-                    words[i] = leaf_word(rank_of[~(t.left != kNone ? t.left : t.right)], 1);
+                    words[i] = leaf_word(e, rank_of[~(t.left != kNone ? t.left : t.right)], 1);
                 }
+            } else if (defer && optimal && (slots[i].in_sub || (!is_sub.empty() && is_sub[c]))) {
+                e.deferred.push_back(Emitter::Deferred{c, depth + 1, me * 32 + 24 + (size_t)i});
+                words[i] = 0;  // set when the pieces are put together
             } else {
-                words[i] = make(c, depth + 1);
+                words[i] = make(e, c, depth + 1, defer);
             }
         }
-        float *dst = &out[me * 32];
+        float *dst = &e.out[me * 32];
         for (int a = 0; a < 6; a++)
             for (int i = 0; i < 4; i++) dst[a * 4 + i] = boxes[a][i];
         std::memcpy(dst + 24, words, 16);
@@ -603,10 +626,10 @@ struct SahBuilder {
 struct SahCollapser {
     const std::vector<SahNode> &sn;
     const std::vector<LeafSlot> &slots;
-    std::vector<float> &out;
+    RawVector<float> &out;
     uint32_t depth_max = 0;
     bool overflow = false;
-    SahCollapser(const std::vector<SahNode> &n, const std::vector<LeafSlot> &s, std::vector<float> &o) : sn(n), slots(s), out(o) {}
+    SahCollapser(const std::vector<SahNode> &n, const std::vector<LeafSlot> &s, RawVector<float> &o) : sn(n), slots(s), out(o) {}
     bool is_leaf(int32_t n) const { return sn[n].left < 0; }
     uint32_t leaf_word(const LeafSlot &s) {
         if (s.first > RT_LEAF_FIRST_MASK || s.count == 0 || s.count > 2) overflow = true;  // the kernels fetch two records per leaf
@@ -845,12 +868,16 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
 
     phase("checks");
     // ---- primitives in declaration order
-    std::vector<uint32_t> rec(total * 12, 0);
-    std::vector<float> nrm(total * 12, 0.0f);
-    std::vector<Box> boxes(total);
+    RawVector<uint32_t> rec(total * 12);  // (every word is written by the record functions)
+    RawVector<float> nrm(total * 12);
+    RawVector<Box> boxes(total);
     struct MeshSpan {
         uint64_t first, count;
     };
+    struct MeshJob {
+        uint64_t object, first;  // scene object, id of its first face
+    };
+    std::vector<MeshJob> mesh_jobs;
     std::vector<Item> world_items;
     std::vector<MeshSpan> mesh_spans;
     std::vector<size_t> mesh_world_slot;
@@ -858,24 +885,6 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
     hs.n_triangles = 0;
     for (uint64_t i = 0; i < d->n_objects; i++) {
         const RtObject &o = d->objects[i];
-        uint32_t mat = (uint32_t)o.material << RT_PRIM_MAT_SHIFT;
-        auto put3 = [&](uint64_t p, int w, V3 v) {
-            rec[p * 12 + w] = fbits(v.x), rec[p * 12 + w + 1] = fbits(v.y), rec[p * 12 + w + 2] = fbits(v.z);
-        };
-        auto tri = [&](uint64_t p, const V3 vv[3], const V3 nn[3], bool two_sided) {
-            put3(p, 0, vv[0]);
-            put3(p, 3, sub(vv[1], vv[0]));
-            put3(p, 6, sub(vv[2], vv[0]));
-            rec[p * 12 + 10] = RT_PRIM_TRIANGLE | (two_sided ? RT_PRIM_FLAG : 0) | mat;
-            rec[p * 12 + 11] = (uint32_t)p;
-            for (int k = 0; k < 3; k++) {
-                nrm[p * 12 + 4 * k] = nn[k].x, nrm[p * 12 + 4 * k + 1] = nn[k].y, nrm[p * 12 + 4 * k + 2] = nn[k].z;
-            }
-            Box &b = boxes[p];  // Triangle::bounding_box (src/tracer/triangle.rs:80-105)
-            b.lo[0] = fmin_(vv[0].x, fmin_(vv[1].x, vv[2].x)), b.hi[0] = fmax_(vv[0].x, fmax_(vv[1].x, vv[2].x));
-            b.lo[1] = fmin_(vv[0].y, fmin_(vv[1].y, vv[2].y)), b.hi[1] = fmax_(vv[0].y, fmax_(vv[1].y, vv[2].y));
-            b.lo[2] = fmin_(vv[0].z, fmin_(vv[1].z, vv[2].z)), b.hi[2] = fmax_(vv[0].z, fmax_(vv[1].z, vv[2].z));
-        };
         switch (o.type) {
             case RT_OBJ_SPHERE:
             case RT_OBJ_ABOX:
@@ -889,23 +898,9 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
                 id++;
                 break;
             }
-            default: {  // RT_OBJ_MESH, Mesh::new (src/tracer/mesh.rs:22-87)
+            default: {  // RT_OBJ_MESH: its faces are made below, side by side with the other meshes
                 const RtMesh &m = d->meshes[o.mesh];
-                Rotor rot = rotor_from_euler(m.rotation[2], m.rotation[0], m.rotation[1]);
-                V3 sc = v3(m.scale[0], m.scale[1], m.scale[2]);
-                V3 tr = v3(m.translation[0], m.translation[1], m.translation[2]);
-                parallel_ranges(m.n_faces, [&](uint64_t f_lo, uint64_t f_hi) {
-                    for (uint64_t f = f_lo; f < f_hi; f++) {
-                        V3 vv[3], nn[3];
-                        for (int k = 0; k < 3; k++) {
-                            uint64_t vi = m.indices[3 * f + k];
-                            V3 p = v3(m.positions[3 * vi], m.positions[3 * vi + 1], m.positions[3 * vi + 2]);
-                            vv[k] = add(rotate(rot, mul(p, sc)), tr);
-                            nn[k] = rotate(rot, v3(m.normals[3 * vi], m.normals[3 * vi + 1], m.normals[3 * vi + 2]));
-                        }
-                        tri(id + f, vv, nn, !m.cull_backface);
-                    }
-                });
+                mesh_jobs.push_back(MeshJob{i, id});
                 mesh_spans.push_back(MeshSpan{id, m.n_faces});
                 mesh_world_slot.push_back(world_items.size());
                 world_items.push_back(Item{kNone, Box{}});  // filled once the mesh tree exists
@@ -913,6 +908,51 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
                 id += m.n_faces;
                 break;
             }
+        }
+    }
+    {
+        // Mesh::new (src/tracer/mesh.rs:22-87) for faces [f_lo, f_hi) of one mesh object
+        auto mesh_faces = [&](const MeshJob &job, uint64_t f_lo, uint64_t f_hi) {
+            const RtObject &o = d->objects[job.object];
+            const RtMesh &m = d->meshes[o.mesh];
+            const uint32_t mat = (uint32_t)o.material << RT_PRIM_MAT_SHIFT;
+            Rotor rot = rotor_from_euler(m.rotation[2], m.rotation[0], m.rotation[1]);
+            V3 sc = v3(m.scale[0], m.scale[1], m.scale[2]);
+            V3 tr = v3(m.translation[0], m.translation[1], m.translation[2]);
+            for (uint64_t f = f_lo; f < f_hi; f++) {
+                float vv[9], nn[9], bx[6];
+                for (int k = 0; k < 3; k++) {
+                    uint64_t vi = m.indices[3 * f + k];
+                    V3 p = v3(m.positions[3 * vi], m.positions[3 * vi + 1], m.positions[3 * vi + 2]);
+                    V3 q = add(rotate(rot, mul(p, sc)), tr);
+                    V3 n = rotate(rot, v3(m.normals[3 * vi], m.normals[3 * vi + 1], m.normals[3 * vi + 2]));
+                    vv[3 * k] = q.x, vv[3 * k + 1] = q.y, vv[3 * k + 2] = q.z;
+                    nn[3 * k] = n.x, nn[3 * k + 1] = n.y, nn[3 * k + 2] = n.z;
+                }
+                const uint64_t p = job.first + f;
+                triangle_record(vv, nn, !m.cull_backface, mat, (uint32_t)p, &rec[p * 12], &nrm[p * 12], bx);
+                for (int k = 0; k < 3; k++) boxes[p].lo[k] = bx[k], boxes[p].hi[k] = bx[3 + k];
+            }
+        };
+        unsigned hw0 = std::thread::hardware_concurrency();
+        hw0 = hw0 ? std::min(hw0, 16u) : 1u;
+        if (mesh_jobs.size() < hw0) {  // few meshes: the threads share each mesh's faces
+            for (const MeshJob &job : mesh_jobs)
+                parallel_ranges(d->meshes[d->objects[job.object].mesh].n_faces,
+                                [&](uint64_t f_lo, uint64_t f_hi) { mesh_faces(job, f_lo, f_hi); });
+        } else {  // many meshes: one mesh at a time per thread
+            std::atomic<size_t> next_job{0};
+            auto worker = [&]() {
+                for (;;) {
+                    size_t j = next_job.fetch_add(1);
+                    if (j >= mesh_jobs.size()) break;
+                    mesh_faces(mesh_jobs[j], 0, d->meshes[d->objects[mesh_jobs[j].object].mesh].n_faces);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned w = 1; w < hw0; w++) pool.emplace_back(worker);
+            worker();
+            for (auto &t : pool) t.join();
         }
     }
 
@@ -972,24 +1012,70 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
         B.nodes.resize(hs.n_binary_nodes);
 
         phase("binary trees (sort + split)");
-        // ---- visit ranks: right child first
-        std::vector<uint32_t> rank_of(total, 0);
+        // ---- subtrees that the passes below work on side by side: the nodes ten levels below the root
+        std::vector<int32_t> subs;
+        std::vector<uint8_t> is_sub(B.nodes.size(), 0);
         {
-            std::vector<int32_t> stack;
-            stack.push_back(root);
-            uint32_t next = 0;
+            std::vector<std::pair<int32_t, int>> stack{{root, 0}};
             while (!stack.empty()) {
-                int32_t c = stack.back();
+                auto [c, depth] = stack.back();
                 stack.pop_back();
-                if (c == kNone) continue;
-                if (c < 0) {
-                    rank_of[~c] = next++;
+                if (c == kNone || c < 0) continue;
+                if (depth == 10) {
+                    subs.push_back(c);
+                    is_sub[c] = 1;
                     continue;
                 }
-                stack.push_back(B.nodes[c].left);   // popped second
-                stack.push_back(B.nodes[c].right);  // popped first
+                stack.push_back({B.nodes[c].left, depth + 1});
+                stack.push_back({B.nodes[c].right, depth + 1});
             }
-            if (next != total) {
+        }
+        auto for_each_sub = [&](auto fn) {  // fn(index into subs), on up to hw threads
+            std::atomic<size_t> next_sub{0};
+            auto worker = [&]() {
+                for (;;) {
+                    size_t i = next_sub.fetch_add(1);
+                    if (i >= subs.size()) break;
+                    fn(i);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned w = 1; w < std::min<size_t>(hw, subs.size()); w++) pool.emplace_back(worker);
+            worker();
+            for (auto &t : pool) t.join();
+        };
+        // ---- visit ranks: right child first.  Primitives below a subtree take consecutive ranks, so the subtrees are
+        // counted side by side, given their first rank by a walk over the top of the tree, and numbered side by side.
+        std::vector<uint32_t> rank_of(total, 0);
+        {
+            std::vector<uint32_t> sub_count(subs.size(), 0), sub_first(subs.size(), 0);
+            std::vector<int32_t> sub_index(B.nodes.size(), -1);
+            for (size_t i = 0; i < subs.size(); i++) sub_index[subs[i]] = (int32_t)i;
+            auto walk = [&](int32_t from, uint32_t next, bool assign, bool top) -> uint32_t {
+                std::vector<int32_t> stack{from};
+                while (!stack.empty()) {
+                    int32_t c = stack.back();
+                    stack.pop_back();
+                    if (c == kNone) continue;
+                    if (c < 0) {
+                        if (assign) rank_of[~c] = next;
+                        next++;
+                        continue;
+                    }
+                    if (top && is_sub[c]) {
+                        sub_first[sub_index[c]] = next;
+                        next += sub_count[sub_index[c]];
+                        continue;
+                    }
+                    stack.push_back(B.nodes[c].left);   // popped second
+                    stack.push_back(B.nodes[c].right);  // popped first
+                }
+                return next;
+            };
+            for_each_sub([&](size_t i) { sub_count[i] = walk(subs[i], 0, false, false); });
+            const uint32_t covered = walk(root, 0, true, true);
+            for_each_sub([&](size_t i) { walk(subs[i], sub_first[i], true, false); });
+            if (covered != total) {
                 err = "internal: visit order does not cover every primitive";
                 return RT_ERR_INTERNAL;
             }
@@ -998,23 +1084,92 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
         phase("visit ranks");
         // ---- wide nodes
         hs.nodes.clear();
-        hs.nodes.reserve((total / 4 + 8) * 32);
         // Default: keep the reference's own interior topology (a spatial-median tree, which on evenly
         // tessellated meshes traverses as well as the SAH rebuild: 21.4 vs 24.7 node visits per ray on
         // the 1 M-triangle bench scene).  RTCORE_INTERIOR=sah selects the rebuild; results are
         // identical either way, only the number of box tests differs.
         const char *interior = std::getenv("RTCORE_INTERIOR");
         if (!(interior && std::strcmp(interior, "sah") == 0)) {
-            Collapser C(B.nodes, rank_of, hs.nodes);
+            Collapser C(B.nodes, rank_of);
             // RTCORE_COLLAPSE=greedy keeps the simpler rule (dissolve the child with the largest box first)
             const char *collapse = std::getenv("RTCORE_COLLAPSE");
-            if (!(collapse && std::strcmp(collapse, "greedy") == 0)) C.plan(root);
-            C.make(root, 1);
-            if (C.overflow) {
+            const bool greedy = collapse && std::strcmp(collapse, "greedy") == 0;
+            if (!greedy) {
+                // the table of every subtree, side by side, then of the top of the tree
+                C.is_sub = is_sub;
+                C.plan_begin();
+                for_each_sub([&](size_t i) { C.plan(subs[i]); });
+                C.plan(root);
+            }
+            // the top of the tree, then the pieces it left to the subtrees, side by side, each into its own emitter
+            Emitter top;
+            C.make(top, root, 1, !greedy);
+            std::vector<Emitter> pieces(top.deferred.size());
+            {
+                std::atomic<size_t> next_piece{0};
+                auto worker = [&]() {
+                    for (;;) {
+                        size_t i = next_piece.fetch_add(1);
+                        if (i >= pieces.size()) break;
+                        C.make(pieces[i], top.deferred[i].node, top.deferred[i].depth, false);
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (unsigned w = 1; w < std::min<size_t>(hw, pieces.size()); w++) pool.emplace_back(worker);
+                worker();
+                for (auto &t : pool) t.join();
+            }
+            // put together: the top first, the pieces after it; node indices inside a piece move by its position
+            std::vector<size_t> base(pieces.size() + 1, 0);
+            base[0] = top.out.size() / 32;
+            bool overflow = top.overflow;
+            uint32_t depth_max = top.depth_max;
+            for (size_t i = 0; i < pieces.size(); i++) {
+                base[i + 1] = base[i] + pieces[i].out.size() / 32;
+                overflow = overflow || pieces[i].overflow;
+                depth_max = std::max(depth_max, pieces[i].depth_max);
+            }
+            if (overflow) {
                 err = "internal: leaf encoding overflow";
                 return RT_ERR_INTERNAL;
             }
-            hs.wide_depth = C.depth_max;
+            if (base.back() >= (1ull << 25)) {  // kernels address nodes with 32-bit byte offsets
+                err = "too many tree nodes";
+                return RT_ERR_INVALID_ARGUMENT;
+            }
+            hs.nodes.resize(base.back() * 32);
+            std::memcpy(hs.nodes.data(), top.out.data(), top.out.size() * 4);
+            for (size_t i = 0; i < pieces.size(); i++) {
+                const uint32_t word = (uint32_t)base[i];
+                std::memcpy(&hs.nodes[top.deferred[i].at], &word, 4);
+            }
+            {
+                std::atomic<size_t> next_piece{0};
+                auto worker = [&]() {
+                    for (;;) {
+                        size_t i = next_piece.fetch_add(1);
+                        if (i >= pieces.size()) break;
+                        float *dst = &hs.nodes[base[i] * 32];
+                        const std::vector<float> &src = pieces[i].out;
+                        std::memcpy(dst, src.data(), src.size() * 4);
+                        for (size_t nd = 0; nd < src.size() / 32; nd++)
+                            for (int c = 0; c < 4; c++) {
+                                uint32_t w;
+                                std::memcpy(&w, dst + nd * 32 + 24 + c, 4);
+                                if (!(w & RT_CHILD_LEAF)) {  // a node of this piece (empty slots and leaves have the bit set)
+                                    w += (uint32_t)base[i];
+                                    std::memcpy(dst + nd * 32 + 24 + c, &w, 4);
+                                }
+                            }
+                        std::vector<float>().swap(pieces[i].out);
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (unsigned w = 1; w < std::min<size_t>(hw, pieces.size()); w++) pool.emplace_back(worker);
+                worker();
+                for (auto &t : pool) t.join();
+            }
+            hs.wide_depth = depth_max;
         } else {
             std::vector<LeafSlot> slots;
             slots.reserve(total);
@@ -1024,6 +1179,7 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
             SahBuilder S(slots);
             S.spare_threads = (int)hw - 1;
             int32_t sroot = S.build(order.data(), order.size());
+            hs.nodes.reserve((total / 4 + 8) * 32);
             SahCollapser C(S.nodes, slots, hs.nodes);
             C.make(sroot, 1);
             if (C.overflow) {
@@ -1058,8 +1214,8 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
 
         phase("wide nodes");
         // ---- records in rank order
-        hs.prims.assign(total * 12, 0);
-        hs.shade_records.assign(total * 24, 0.0f);
+        hs.prims.resize(total * 12);
+        hs.shade_records.resize(total * 24);
         parallel_ranges(total, [&](uint64_t p_lo, uint64_t p_hi) {
             for (uint64_t p = p_lo; p < p_hi; p++) {
                 uint64_t r = rank_of[p];
