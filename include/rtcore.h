@@ -240,11 +240,12 @@ int rt_scene_create_replicas(const RtSceneDesc *desc, const int *devices, int n,
  * Which build makes the tree.
  *   RT_BUILD_EXACT   (the default) restates Bvh::new on the host (src/tracer/bvh.rs:39-117): the reference's tree,
  *                    hence the reference's winner among hits at exactly the same t (see "Equal distances" above).
- *   RT_BUILD_DEVICE  builds on the GPU with no host sort: primitive boxes, Morton order, binary radix tree, the same
+ *   RT_BUILD_DEVICE  builds on the GPU: primitive boxes, the reference's median splits level by level (no sort), the same
  *                    4-wide collapse.  Primitive records are the same bits as the exact build's, so (prim_id, t,
  *                    normal) are the same for every ray whose closest hit is not an exact tie between two primitives
  *                    (which of the two is named then follows this tree's order, not the reference's) and that does not
- *                    graze a leaf's guard box within rounding.  Two orders of magnitude faster on large meshes.
+ *                    graze a leaf's guard box within rounding.  Tens of times faster on large meshes, same traversal
+ *                    speed.
  *   RT_BUILD_DEFAULT RT_BUILD_DEVICE when the environment has RTCORE_BUILD=gpu, else RT_BUILD_EXACT.
  * rt_scene_create(desc, out) is rt_scene_create_with(desc, RT_BUILD_DEFAULT, out).
  */

@@ -1189,8 +1189,14 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
             hs.wide_depth = C.depth_max;
         }
         hs.n_nodes = hs.nodes.size() / 32;
+        if (std::getenv("RTCORE_DEBUG_TREE")) {
+            double sum = 0.0;
+            for (const BNode &nd : B.nodes) sum += half_area(nd.box);
+            std::fprintf(stderr, "[rtcore] binary tree: %zu nodes, summed half area %.6g\n", B.nodes.size(), sum);
+        }
         if (std::getenv("RTCORE_DEBUG_TREE")) {  // surface-area cost of the wide tree, for comparing builders
             double inner = 0.0, leaf = 0.0;
+            size_t n_leaf1 = 0, n_leaf2 = 0, n_inner_slots = 0;
             for (size_t nd = 0; nd < hs.nodes.size() / 32; nd++) {
                 const float *f = &hs.nodes[nd * 32];
                 uint32_t w[4];
@@ -1199,11 +1205,11 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
                     if (w[c] == RT_CHILD_NONE) continue;
                     double dx = f[12 + c] - f[c], dy = f[16 + c] - f[4 + c], dz = f[20 + c] - f[8 + c];
                     double a = dx * dy + dy * dz + dz * dx;
-                    if (w[c] & RT_CHILD_LEAF) leaf += a; else inner += a;
+                    if (w[c] & RT_CHILD_LEAF) { leaf += a; if ((w[c] >> 28) & 7u) n_leaf2++; else n_leaf1++; } else { inner += a; n_inner_slots++; }
                 }
             }
-            std::fprintf(stderr, "[rtcore] wide tree: %zu nodes, summed half area of node children %.6g, of leaf children %.6g\n",
-                         hs.nodes.size() / 32, inner, leaf);
+            std::fprintf(stderr, "[rtcore] wide tree: %zu nodes, summed half area of node children %.6g, of leaf children %.6g; %zu node slots, %zu single and %zu pair leaf slots\n",
+                         hs.nodes.size() / 32, inner, leaf, n_inner_slots, n_leaf1, n_leaf2);
         }
         if (hs.n_nodes >= (1ull << 25)) {  // kernels address nodes with 32-bit byte offsets
             err = "too many tree nodes";

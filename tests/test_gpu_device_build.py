@@ -110,6 +110,17 @@ def test_coincident_twins_differ_only_in_which_twin_is_named(pkg, oracle):
     print("coincident twins: %d of %d hits name the other twin" % (len(bad), int(hit.sum())))
 
 
+def test_morton_order_tree_gives_the_same_hits(pkg, oracle, monkeypatch):
+    """RTCORE_DEVICE_TREE=morton: the other binary tree of the device build (Morton codes, radix sort, binary radix
+    tree).  Same records and guard boxes, so the same hits; only the number of box tests differs."""
+    monkeypatch.setenv("RTCORE_DEVICE_TREE", "morton")
+    d = pkg.scenes.mesh_scene(n_triangles=100_000, rings=24, segments=24, seed=11)
+    mn, mx = oracle.OracleScene(d).bounds()
+    rays = pkg.scenes.random_rays(300_000, mn, mx, seed=17, inflate=1.2)
+    bad, got, want = _compare(pkg, oracle, d, rays)
+    assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32)) and len(bad) <= 3
+
+
 def test_bad_vertex_index_and_degenerate_input(pkg):
     S = pkg.SceneDescription()
     m = S.add_material(pkg.lambertian((0.5, 0.5, 0.5)))
@@ -117,13 +128,15 @@ def test_bad_vertex_index_and_degenerate_input(pkg):
     with pytest.raises(pkg.RtError) as e:
         pkg.Scene(S, builder=pkg._abi.RT_BUILD_DEVICE)
     assert e.value.code == pkg._abi.RT_ERR_INVALID_ARGUMENT and "vertex index" in str(e.value)
-    # 5000 identical triangles (one Morton code) and a NaN vertex: the build terminates and the scene answers
+    # 5000 identical triangles and one with a NaN vertex (a smaller box beside 5000 equal ones: the reference would split
+    # the equal ones off one by one, 5000 levels deep): the build terminates with a shallow tree and the scene answers
     S = pkg.SceneDescription()
     m = S.add_material(pkg.lambertian((0.5, 0.5, 0.5)))
     pos = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0], [np.nan, 0, 0]])
     idx = np.concatenate([np.tile(np.uint32([[0, 1, 2]]), (5000, 1)), np.uint32([[0, 1, 3]])])
     S.add_mesh(pos, np.tile(np.float32([0, 0, 1]), (4, 1)), idx, m)
     scene = pkg.Scene(S, builder=pkg._abi.RT_BUILD_DEVICE)
+    assert scene.info().wide_depth < 40
     ids, t, _, _ = scene.closest_hit(np.float32([[0.2, 0.2, -1, 0, 0, 1], [5, 5, -1, 0, 0, 1]]))
     assert 0 <= ids[0] < 5000 and t[0] == 1.0 and ids[1] == -1
     scene.close()
