@@ -219,7 +219,9 @@ def main():
     cs = scene.stats()
     visits_per_ray = cs.node_visits / max(1, cs.rays)
     tests_per_ray = cs.prim_tests / max(1, cs.rays)
-    bytes_per_ray = visits_per_ray * info.node_bytes + tests_per_ray * info.primitive_bytes + 32 + 8
+    # compact nodes (64 B) come with a 32-byte guard box per leaf visit; the 128-byte nodes hold the guards themselves
+    guard_bytes_per_ray = 32.0 * cs.leaf_step_lanes / max(1, cs.rays) if info.node_bytes == 64 else 0.0
+    bytes_per_ray = visits_per_ray * info.node_bytes + guard_bytes_per_ray + tests_per_ray * info.primitive_bytes + 32 + 8
     lookups_per_ray = cs.l1_lookups / max(1, cs.rays)
     steps_counted = cs.node_steps + cs.leaf_steps
     step_lane_occupancy = ((cs.node_step_lanes + cs.leaf_step_lanes) / (64.0 * steps_counted)) if steps_counted else None
@@ -384,7 +386,7 @@ def main():
                 "s_per_4k_frame": round(elapsed_max / max(1, my_steps), 4) if (W, H) == (3840, 2160) else None,
                 "rays_per_step_per_gpu": int(st.rays / max(1, my_steps)),
                 "scene_gen_s": round(t_gen, 2), "scene_build_s": round(t_build, 2),
-                "builder": args.builder, "scene_build_ms_library": round(info.build_ms, 1), "wide_depth": int(info.wide_depth),
+                "builder": args.builder, "node_bytes": int(info.node_bytes), "scene_build_ms_library": round(info.build_ms, 1), "wide_depth": int(info.wide_depth),
             },
             "roofline": roof,
         }

@@ -431,15 +431,10 @@ RT_DEV void node_fetch_own(const RtSceneView &sc, uint32_t entry, NodeWords &w) 
     w.cwf = *(const float4 *)(nodes + (base + 96u));
 }
 
-// tr.entry is a node whose words are `w`: tests its four child boxes, pushes the far hits and continues with the
-// nearest.  Returns true when no child was hit: the lane then wants the next stack entry.
-template <bool COUNT>
-RT_DEV bool traversal_node_process(const NodeWords &w, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
-    if (COUNT) (*visits)++;
-    float key[4];
-    uint32_t cw[4];
-    // the hit children are the pairs [4 - nh, 4), nearest first
-    const int nh = node_children_sorted(w.nx4, w.ny4, w.nz4, w.fx4, w.fy4, w.fz4, w.cwf, tr.ray.o, tr.inv, t_min, tr.best.t, key, cw);
+// After the slab tests of a node step: pushes the far hit children and continues with the nearest.  `key` / `cw` are the
+// sorted pairs (the hit children are the pairs [4 - nh, 4), nearest first).  Returns true when no child was hit: the lane
+// then wants the next stack entry.
+RT_DEV bool traversal_descend(const int nh, const float key[4], const uint32_t cw[4], Traversal &tr, Stack &st) {
     // The farthest goes to the stack first, the nearest continues.  Pairs 3, 2, 1 are written to the three entries above
     // the top whether they are hit children or not: what is not one lies above the new top, where nothing reads it.
     if (st.sp + 3 <= RT_LDS_STACK) {
@@ -457,11 +452,180 @@ RT_DEV bool traversal_node_process(const NodeWords &w, Traversal &tr, Stack &st,
     return nh == 0;
 }
 
+// tr.entry is a node whose words are `w`: tests its four child boxes, pushes the far hits and continues with the
+// nearest.  Returns true when no child was hit: the lane then wants the next stack entry.
+template <bool COUNT>
+RT_DEV bool traversal_node_process(const NodeWords &w, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
+    if (COUNT) (*visits)++;
+    float key[4];
+    uint32_t cw[4];
+    const int nh = node_children_sorted(w.nx4, w.ny4, w.nz4, w.fx4, w.fy4, w.fz4, w.cwf, tr.ray.o, tr.inv, t_min, tr.best.t, key, cw);
+    return traversal_descend(nh, key, cw, tr, st);
+}
+
 template <bool COUNT>
 RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
     NodeWords w;
     node_fetch_own(sc, tr.entry, w);
     return traversal_node_process<COUNT>(w, tr, st, t_min, visits);
+}
+
+// ---- the same walk over compact nodes (rt_types.h) -----------------------------------------------------------
+// A compact child box contains the exact one, and the slab test is monotone in the box, so a ray that the reference's
+// test lets into a leaf's guard box gets through every compact box above it PROVIDED the arithmetic here never rejects
+// what exact arithmetic on the compact box would accept.  The distance to plane k is evaluated as k * A + B with
+// A = step / d and B = (origin - o) / d per axis; against the reference's two roundings on the guard box and the
+// roundings here, the near distances are lowered and the far distances raised by kGridSlack * (|B| + 255 |A|), which
+// bounds every plane distance of the node on that axis (2^-20 of it: sixteen roundings' worth).  An axis whose A or B
+// is not finite (d = 0, overflow) yields NaN or -inf / +inf there and is ignored by the NaN-ignoring min / max, which
+// again only lets more rays through.  Entry distances of compact boxes are lower bounds: they order the children and
+// drop stack entries beyond the best hit, nothing else.
+constexpr float kGridSlack = 9.5367431640625e-07f;  // 2^-20
+
+struct QNodeWords {
+    float4 a, b, c, cwf;
+};
+
+RT_DEV void qnode_fetch_own(const RtSceneView &sc, uint32_t entry, QNodeWords &w) {
+    const char *__restrict__ nodes = (const char *)sc.qnodes;
+    const uint32_t base = entry * (RT_QNODE_FLOAT4S * 16u);
+    w.a = *(const float4 *)(nodes + (base + 0u));
+    w.b = *(const float4 *)(nodes + (base + 16u));
+    w.c = *(const float4 *)(nodes + (base + 32u));
+    w.cwf = *(const float4 *)(nodes + (base + 48u));
+}
+
+template <int K>
+RT_DEV float grid_byte(uint32_t v) {
+    return (float)((v >> (8 * K)) & 0xffu);  // v_cvt_f32_ubyteK
+}
+
+struct GridAxis {
+    float a, b_near, b_far, bound;
+    uint32_t q_near, q_far;
+};
+RT_DEV GridAxis grid_axis(float origin, float step, uint32_t q_lo, uint32_t q_hi, float o, float inv) {
+    GridAxis g;
+    g.a = step * inv;
+    const float b = (origin - o) * inv;
+    g.bound = fmaf(fabsf(g.a), 255.0f, fabsf(b));
+    g.b_near = fmaf(-kGridSlack, g.bound, b);
+    g.b_far = fmaf(kGridSlack, g.bound, b);
+    const bool neg = inv < 0.0f;  // the planes swap roles for a ray that runs down the axis
+    g.q_near = neg ? q_hi : q_lo;
+    g.q_far = neg ? q_lo : q_hi;
+    return g;
+}
+
+template <int C>
+RT_DEV bool grid_child(const GridAxis &x, const GridAxis &y, const GridAxis &z, uint32_t word, float t_min, float t_best,
+                       float *key) {
+    const float tn = fmaxf(fmaxf(fmaxf(fmaf(grid_byte<C>(x.q_near), x.a, x.b_near), fmaf(grid_byte<C>(y.q_near), y.a, y.b_near)),
+                                 fmaf(grid_byte<C>(z.q_near), z.a, z.b_near)),
+                           t_min);
+    const float tf = fminf(fminf(fminf(fmaf(grid_byte<C>(x.q_far), x.a, x.b_far), fmaf(grid_byte<C>(y.q_far), y.a, y.b_far)),
+                                 fmaf(grid_byte<C>(z.q_far), z.a, z.b_far)),
+                           t_best);
+    const bool hit = (tn <= tf) && (word != RT_CHILD_NONE);
+    *key = hit ? tn : __int_as_float(0xff800000);
+    return hit;
+}
+
+// The rare ray for which A or B is not finite on some axis (it runs parallel to an axis: 1 / d is infinite; or
+// something overflowed; or the node has an open axis): every plane is worked out, origin + k * step in one rounding --
+// a low plane still at or below the exact box's, a high plane at or above -- and goes through the reference's formula,
+// which handles those cases the way the reference does (a parallel ray outside the slab is turned away; ignoring the
+// axis instead would send a ray that runs along an axis through every node its line of sight never leaves).
+template <int C>
+RT_DEV bool plane_child(const QNodeWords &w, uint32_t word, const F3 o, const F3 inv, float t_min, float t_best, float *key) {
+    const F3 lo = f3(fmaf(grid_byte<C>(__float_as_uint(w.b.z)), w.a.w, w.a.x), fmaf(grid_byte<C>(__float_as_uint(w.b.w)), w.b.x, w.a.y),
+                     fmaf(grid_byte<C>(__float_as_uint(w.c.x)), w.b.y, w.a.z));
+    const F3 hi = f3(fmaf(grid_byte<C>(__float_as_uint(w.c.y)), w.a.w, w.a.x), fmaf(grid_byte<C>(__float_as_uint(w.c.z)), w.b.x, w.a.y),
+                     fmaf(grid_byte<C>(__float_as_uint(w.c.w)), w.b.y, w.a.z));
+    const F3 t0 = (lo - o) * inv, t1 = (hi - o) * inv;
+    const float tn = fmaxf(max3(f3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z))), t_min);
+    const float tf = fminf(min3(f3(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z))), t_best);
+    const bool hit = (tn <= tf) && (word != RT_CHILD_NONE);
+    *key = hit ? tn : __int_as_float(0xff800000);
+    return hit;
+}
+
+RT_DEV int qnode_children_sorted(const QNodeWords &w, const F3 o, const F3 inv, float t_min, float t_best, float key[4],
+                                 uint32_t cw[4]) {
+    cw[0] = __float_as_uint(w.cwf.x), cw[1] = __float_as_uint(w.cwf.y), cw[2] = __float_as_uint(w.cwf.z), cw[3] = __float_as_uint(w.cwf.w);
+    const GridAxis x = grid_axis(w.a.x, w.a.w, __float_as_uint(w.b.z), __float_as_uint(w.c.y), o.x, inv.x);
+    const GridAxis y = grid_axis(w.a.y, w.b.x, __float_as_uint(w.b.w), __float_as_uint(w.c.z), o.y, inv.y);
+    const GridAxis z = grid_axis(w.a.z, w.b.y, __float_as_uint(w.c.x), __float_as_uint(w.c.w), o.z, inv.z);
+    int nh = 0;
+    nh += grid_child<0>(x, y, z, cw[0], t_min, t_best, &key[0]) ? 1 : 0;
+    nh += grid_child<1>(x, y, z, cw[1], t_min, t_best, &key[1]) ? 1 : 0;
+    nh += grid_child<2>(x, y, z, cw[2], t_min, t_best, &key[2]) ? 1 : 0;
+    nh += grid_child<3>(x, y, z, cw[3], t_min, t_best, &key[3]) ? 1 : 0;
+    const float kHuge = 3.0e38f;
+    if (!(x.bound < kHuge && y.bound < kHuge && z.bound < kHuge)) {
+        nh = plane_child<0>(w, cw[0], o, inv, t_min, t_best, &key[0]) ? 1 : 0;
+        nh += plane_child<1>(w, cw[1], o, inv, t_min, t_best, &key[1]) ? 1 : 0;
+        nh += plane_child<2>(w, cw[2], o, inv, t_min, t_best, &key[2]) ? 1 : 0;
+        nh += plane_child<3>(w, cw[3], o, inv, t_min, t_best, &key[3]) ? 1 : 0;
+    }
+#define RT_CSEL(i, j)                                   \
+    {                                                   \
+        const bool sw = key[j] < key[i];                \
+        const float ki = sw ? key[j] : key[i];          \
+        const float kj = sw ? key[i] : key[j];          \
+        const uint32_t wi = sw ? cw[j] : cw[i];         \
+        const uint32_t wj = sw ? cw[i] : cw[j];         \
+        key[i] = ki, key[j] = kj, cw[i] = wi, cw[j] = wj; \
+    }
+    RT_CSEL(0, 1) RT_CSEL(2, 3) RT_CSEL(0, 2) RT_CSEL(1, 3) RT_CSEL(1, 2)
+#undef RT_CSEL
+    return nh;
+}
+
+template <bool COUNT>
+RT_DEV bool traversal_qnode_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
+    QNodeWords w;
+    qnode_fetch_own(sc, tr.entry, w);
+    if (COUNT) (*visits)++;
+    float key[4];
+    uint32_t cw[4];
+    const int nh = qnode_children_sorted(w, tr.ray.o, tr.inv, t_min, tr.best.t, key, cw);
+    return traversal_descend(nh, key, cw, tr, st);
+}
+
+// tr.entry is a leaf reached through compact boxes: its guard box -- the box the reference tests last before these
+// primitives -- is tested first, by the reference's formula, and the primitives count only if the ray gets through it.
+template <bool COUNT>
+RT_DEV void traversal_guarded_leaf_step(const RtSceneView &sc, Traversal &tr, float t_min, float t_max, uint32_t *tests) {
+    const float4 *__restrict__ prims = (const float4 *)sc.prims;
+    const uint32_t entry = tr.entry;
+    const int32_t first = (int32_t)(entry & RT_LEAF_FIRST_MASK);
+    const int32_t count = (int32_t)((entry >> 28) & 7u) + 1;
+    const float4 *g = (const float4 *)sc.guards + (size_t)first * RT_GUARD_FLOAT4S;
+    const float4 *r = prims + (size_t)first * RT_PRIM_FLOAT4S;
+    const bool two = count > 1;
+    const float4 g0 = g[0], g1 = g[1];
+    float4 a0 = r[0], a1 = r[1], a2 = r[2];
+    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 b0 = zero, b1 = zero, b2 = zero;
+    if (two) b0 = r[3], b1 = r[4], b2 = r[5];
+    // src/tracer/cube.rs:163-171 on the guard box
+    const F3 t0 = (f3(g0.x, g0.y, g0.z) - tr.ray.o) * tr.inv;
+    const F3 t1 = (f3(g0.w, g1.x, g1.y) - tr.ray.o) * tr.inv;
+    const float tn = fmaxf(max3(f3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z))), t_min);
+    const float tf = fminf(min3(f3(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z))), tr.best.t);
+    const bool open = tn <= tf;
+    if (COUNT) (*tests) += open ? (uint32_t)count : 0u;
+    Best b = tr.best;
+    test_record(a0, a1, a2, first, tr.ray, tr.inv, t_min, t_max, b);
+    if (two) test_record(b0, b1, b2, first + 1, tr.ray, tr.inv, t_min, t_max, b);
+    for (int32_t k = 2; k < count; k++) {
+        const float4 *q = prims + (size_t)(first + k) * RT_PRIM_FLOAT4S;
+        test_record(q[0], q[1], q[2], first + k, tr.ray, tr.inv, t_min, t_max, b);
+    }
+    tr.best.t = open ? b.t : tr.best.t;
+    tr.best.index = open ? b.index : tr.best.index;
+    tr.best.ties = open ? b.ties : tr.best.ties;
 }
 
 }  // namespace rtd

@@ -107,7 +107,10 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
 #define RT_RAY_CHUNK 256
 #endif
 #ifndef RT_SERVICE_LANES
-#define RT_SERVICE_LANES 40
+#define RT_SERVICE_LANES 24
+#endif
+#ifndef RT_SERVICE_LANES_WIDE
+#define RT_SERVICE_LANES_WIDE 40
 #endif
 #ifndef RT_EXTEND_WAVES
 #define RT_EXTEND_WAVES 7
@@ -125,7 +128,9 @@ constexpr uint32_t kVoteNodeWeight = RT_VOTE_NODE_WEIGHT;
 #endif
 constexpr int kPopTurns = RT_POP_TURNS;
 constexpr uint32_t kRayChunk = RT_RAY_CHUNK;
-constexpr uint32_t kServiceLanes = RT_SERVICE_LANES;
+// refill threshold: over the compact nodes / over the 128-byte nodes (whose fetches cost more, so that rays refilled
+// together -- they walk the upper tree together and share its lines -- are worth more idle lanes)
+constexpr uint32_t kServiceLanesCompact = RT_SERVICE_LANES, kServiceLanesWide = RT_SERVICE_LANES_WIDE;
 
 // Number of different values of `v` among the lanes with `on` (instrumented builds only: one turn per value).
 __device__ __forceinline__ uint32_t wave_distinct(bool on, uint32_t v) {
@@ -139,12 +144,13 @@ __device__ __forceinline__ uint32_t wave_distinct(bool on, uint32_t v) {
     return n;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool COMPACT>
 __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     extend_kernel(RtSceneView sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
                   const uint32_t *__restrict__ count_ptr, uint32_t n_fixed, float t_min, float t_max,
                   float2 *__restrict__ hit, uint2 *ovf, uint32_t *head, unsigned long long *counters) {
     __shared__ uint2 s_stack[RT_LDS_STACK * kBlock];
+    constexpr uint32_t kServiceLanes = COMPACT ? kServiceLanesCompact : kServiceLanesWide;
     const uint32_t n = count_ptr ? *count_ptr : n_fixed;
     const uint32_t lane = threadIdx.x & 63u;
     Stack st;
@@ -238,19 +244,24 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
             // lanes address (a node is seven loads from one line; a primitive record is three loads, 48 bytes that may
             // straddle two lines).  Lanes at the same node or in the same line share a look-up.
             uint32_t lk = 0;
-            if (run_node && n_node) lk += 7u * wave_distinct(at_node, tr.entry);
+            if (run_node && n_node) lk += COMPACT ? 4u * wave_distinct(at_node, tr.entry >> 1) : 7u * wave_distinct(at_node, tr.entry);
             if (run_leaf && n_leaf) {
                 const uint32_t byte0 = (tr.entry & RT_LEAF_FIRST_MASK) * (RT_PRIM_FLOAT4S * 16u);
                 const bool two = ((tr.entry >> 28) & 7u) != 0u;
                 for (uint32_t k = 0; k < 6u; k++) lk += wave_distinct(at_leaf && (k < 3u || two), (byte0 + 16u * k) >> 7);
+                if (COMPACT) lk += 2u * wave_distinct(at_leaf, (tr.entry & RT_LEAF_FIRST_MASK) >> 2);  // the 32-byte guard
             }
             lookups += lk;
         }
         if (run_leaf && at_leaf) {
-            traversal_leaf_step<COUNT>(sc, tr, t_min, t_max, &tests);
+            if (COMPACT)
+                traversal_guarded_leaf_step<COUNT>(sc, tr, t_min, t_max, &tests);
+            else
+                traversal_leaf_step<COUNT>(sc, tr, t_min, t_max, &tests);
             popping = true;
         }
-        if (run_node && at_node) popping = traversal_node_step<COUNT>(sc, tr, st, t_min, &visits);
+        if (run_node && at_node)
+            popping = COMPACT ? traversal_qnode_step<COUNT>(sc, tr, st, t_min, &visits) : traversal_node_step<COUNT>(sc, tr, st, t_min, &visits);
         // Next entry for the lanes that want one.  After a hit most of a ray's stack is beyond the
         // best distance and is dropped entry by entry; a wave waits for its slowest lane (an unbounded
         // loop here took 5.1 turns per leaf step and 1.5 per node step), so each step is followed by
@@ -269,6 +280,76 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
             for (int k = 0; k < 8; k++) atomicAdd(&counters[2 + k], dbg[k]);
             atomicAdd(&counters[14], lookups);
         }
+    }
+}
+
+// The compact nodes and the leaf guards, made from the 128-byte nodes (one thread per node; rt_types.h has the layout).
+// Per axis the grid starts at the lowest plane of the node's children and its step is the smallest power of two with
+// 255 steps reaching the highest; a child's low planes are rounded down to the grid and its high planes up.  An axis
+// on which some child's box is not finite (a NaN or infinite vertex) or which no such grid spans gets an infinite step:
+// the traversal then ignores that axis for every child of the node.
+__global__ void __launch_bounds__(kBlock) compact_nodes_kernel(const float4 *__restrict__ nodes, uint32_t n_nodes,
+                                                               float4 *__restrict__ qnodes, float4 *__restrict__ guards) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_nodes) return;
+    const float4 *nd = nodes + (size_t)i * RT_NODE_FLOAT4S;
+    float4 plane[6];
+    for (int k = 0; k < 6; k++) plane[k] = nd[k];
+    const float4 cwf = nd[6];
+    const uint32_t cw[4] = {__float_as_uint(cwf.x), __float_as_uint(cwf.y), __float_as_uint(cwf.z), __float_as_uint(cwf.w)};
+    float origin[3], step[3];
+    uint32_t qlo[3], qhi[3];
+    for (int a = 0; a < 3; a++) {
+        const float lo[4] = {plane[a].x, plane[a].y, plane[a].z, plane[a].w};
+        const float hi[4] = {plane[a + 3].x, plane[a + 3].y, plane[a + 3].z, plane[a + 3].w};
+        double mn = 1e300, mx = -1e300;
+        bool open = false, any = false;
+        for (int c = 0; c < 4; c++) {
+            if (cw[c] == RT_CHILD_NONE) continue;
+            any = true;
+            if (!(fabsf(lo[c]) <= 3.0e38f) || !(fabsf(hi[c]) <= 3.0e38f) || !(lo[c] <= hi[c]))
+                open = true;
+            else
+                mn = fmin(mn, (double)lo[c]), mx = fmax(mx, (double)hi[c]);
+        }
+        origin[a] = 0.0f, step[a] = __int_as_float(0x7f800000), qlo[a] = 0u, qhi[a] = 0u;
+        if (!any || open) continue;
+        const double ext = mx - mn;
+        double s = 0x1p-100;
+        if (ext > 0.0) {
+            int e;
+            (void)frexp(ext / 255.0, &e);  // ext / 255 = f * 2^e with f in [0.5, 1)
+            s = ldexp(1.0, e - 1);
+            if (s < 0x1p-100) s = 0x1p-100;
+            while (s * 255.0 < ext) s *= 2.0;
+        }
+        if (s > 0x1p100) continue;
+        origin[a] = (float)mn;
+        step[a] = (float)s;
+        for (int c = 0; c < 4; c++) {
+            if (cw[c] == RT_CHILD_NONE) continue;
+            double l = floor(((double)lo[c] - mn) / s), h = ceil(((double)hi[c] - mn) / s);
+            l = fmin(fmax(l, 0.0), 255.0), h = fmin(fmax(h, 0.0), 255.0);
+            qlo[a] |= (uint32_t)l << (8 * c);
+            qhi[a] |= (uint32_t)h << (8 * c);
+        }
+    }
+    float4 *q = qnodes + (size_t)i * RT_QNODE_FLOAT4S;
+    q[0] = make_float4(origin[0], origin[1], origin[2], step[0]);
+    q[1] = make_float4(step[1], step[2], __uint_as_float(qlo[0]), __uint_as_float(qlo[1]));
+    q[2] = make_float4(__uint_as_float(qlo[2]), __uint_as_float(qhi[0]), __uint_as_float(qhi[1]), __uint_as_float(qhi[2]));
+    q[3] = cwf;
+    for (int c = 0; c < 4; c++) {
+        if (cw[c] == RT_CHILD_NONE || !(cw[c] & RT_CHILD_LEAF)) continue;
+        const float l[3] = {c == 0 ? plane[0].x : c == 1 ? plane[0].y : c == 2 ? plane[0].z : plane[0].w,
+                            c == 0 ? plane[1].x : c == 1 ? plane[1].y : c == 2 ? plane[1].z : plane[1].w,
+                            c == 0 ? plane[2].x : c == 1 ? plane[2].y : c == 2 ? plane[2].z : plane[2].w};
+        const float h[3] = {c == 0 ? plane[3].x : c == 1 ? plane[3].y : c == 2 ? plane[3].z : plane[3].w,
+                            c == 0 ? plane[4].x : c == 1 ? plane[4].y : c == 2 ? plane[4].z : plane[4].w,
+                            c == 0 ? plane[5].x : c == 1 ? plane[5].y : c == 2 ? plane[5].z : plane[5].w};
+        float4 *g = guards + (size_t)(cw[c] & RT_LEAF_FIRST_MASK) * RT_GUARD_FLOAT4S;
+        g[0] = make_float4(l[0], l[1], l[2], h[0]);
+        g[1] = make_float4(h[1], h[2], 0.0f, 0.0f);
     }
 }
 
@@ -632,7 +713,8 @@ struct RtScene {
     int device = 0;
     int n_cus = 256;
     rtcore::HostScene host;  // metadata only after upload (big arrays are released)
-    DevBuf nodes, prims, shade_records, materials, env;
+    DevBuf nodes, qnodes, guards, prims, shade_records, materials, env;
+    bool compact = false;  // the closest-hit kernel walks the compact nodes (RTCORE_NODES=compact)
     RtSceneView view{};
     // work buffers
     DevBuf st_o[2], st_d[2], st_thr[2], hit_a, rad, counts, totals, ovf, counters, accum_tmp, io_a, io_b, io_c,
@@ -656,9 +738,11 @@ struct RtScene {
 namespace {
 
 // persistent waves: a launch is as many blocks as are resident at once
-uint32_t resident_extend_blocks(int n_cus) {
+uint32_t resident_extend_blocks(int n_cus, bool compact) {
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, extend_kernel<false>, kBlock, 0) != hipSuccess || per_cu < 1)
+    const hipError_t e = compact ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, extend_kernel<false, true>, kBlock, 0)
+                                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, extend_kernel<false, false>, kBlock, 0);
+    if (e != hipSuccess || per_cu < 1)
         per_cu = 4;
     return (uint32_t)n_cus * (uint32_t)per_cu;
 }
@@ -689,7 +773,7 @@ int ensure_work(RtScene *s, uint64_t paths) {
             per_cu = 4;
         s->pool_blocks = (uint32_t)s->n_cus * (uint32_t)per_cu;
     }
-    if (!s->extend_blocks) s->extend_blocks = resident_extend_blocks(s->n_cus);
+    if (!s->extend_blocks) s->extend_blocks = resident_extend_blocks(s->n_cus, s->compact);
     uint32_t deep = s->view.max_stack > RT_LDS_STACK ? s->view.max_stack - RT_LDS_STACK : 0;
     size_t ovf_bytes = (size_t)deep * s->extend_blocks * kBlock * sizeof(uint2);
     if (s->pooled) {
@@ -752,14 +836,10 @@ int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4
         RT_HIP(hipGetLastError());
         return RT_OK;
     }
-    if (counted)
-        hipLaunchKernelGGL(extend_kernel<true>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
-                           n_upper, t_min, t_max, (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head,
-                           (unsigned long long *)s->counters.p);
-    else
-        hipLaunchKernelGGL(extend_kernel<false>, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr,
-                           n_upper, t_min, t_max, (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head,
-                           (unsigned long long *)s->counters.p);
+    auto kernel = counted ? (s->compact ? extend_kernel<true, true> : extend_kernel<true, false>)
+                          : (s->compact ? extend_kernel<false, true> : extend_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr, n_upper, t_min, t_max,
+                       (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head, (unsigned long long *)s->counters.p);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -955,15 +1035,18 @@ static int upload_scene(const rtcore::HostScene &h, rtcore::DeviceBuild *dev, co
     hipDeviceProp_t prop;
     RT_HIP(hipGetDeviceProperties(&prop, s->device));
     s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    s->extend_blocks = resident_extend_blocks(s->n_cus);
     if (const char *e = std::getenv("RTCORE_EXTEND")) s->pooled = std::string(e) == "pool";
+    // RTCORE_NODES=wide keeps the 128-byte nodes for the closest-hit kernel (the pooled form reads only those)
+    s->compact = !s->pooled;
+    if (const char *e = std::getenv("RTCORE_NODES")) s->compact = s->compact && std::string(e) != "wide";
+    if (peer) s->compact = peer->compact, s->pooled = peer->pooled;
+    s->extend_blocks = resident_extend_blocks(s->n_cus, s->compact);
     int rc;
     auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
         if (bytes == 0) return RT_OK;
         int r = b.ensure(bytes + 128);  // 128 spare bytes, see ensure_work
         if (r) return r;
         RT_HIP(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
-        s->device_bytes += bytes;
         return RT_OK;
     };
     if (dev) {
@@ -971,7 +1054,6 @@ static int upload_scene(const rtcore::HostScene &h, rtcore::DeviceBuild *dev, co
         s->prims.p = dev->prims, s->prims.bytes = dev->prims_bytes;
         s->shade_records.p = dev->shade_records, s->shade_records.bytes = dev->shade_bytes;
         dev->nodes = dev->prims = dev->shade_records = nullptr;
-        s->device_bytes += h.n_nodes * 128 + h.n_prims * (48 + 96);
     } else if (peer) {
         auto copy = [&](DevBuf &b, const DevBuf &from) -> int {
             if (!from.p) return RT_OK;
@@ -980,9 +1062,9 @@ static int upload_scene(const rtcore::HostScene &h, rtcore::DeviceBuild *dev, co
             RT_HIP(hipMemcpyPeer(b.p, s->device, from.p, peer->device, from.bytes));
             return RT_OK;
         };
-        if ((rc = copy(s->nodes, peer->nodes)) || (rc = copy(s->prims, peer->prims)) || (rc = copy(s->shade_records, peer->shade_records)))
+        if ((rc = copy(s->nodes, peer->nodes)) || (rc = copy(s->qnodes, peer->qnodes)) || (rc = copy(s->guards, peer->guards)) ||
+            (rc = copy(s->prims, peer->prims)) || (rc = copy(s->shade_records, peer->shade_records)))
             return rc;
-        s->device_bytes += h.n_nodes * 128 + h.n_prims * (48 + 96);
     } else {
         if ((rc = upload(s->nodes, h.nodes.data(), h.nodes.size() * 4))) return rc;
         if ((rc = upload(s->prims, h.prims.data(), h.prims.size() * 4))) return rc;
@@ -990,8 +1072,22 @@ static int upload_scene(const rtcore::HostScene &h, rtcore::DeviceBuild *dev, co
     }
     if ((rc = upload(s->materials, h.materials.data(), h.materials.size() * sizeof(RtDevMaterial)))) return rc;
     if ((rc = upload(s->env, h.env.data(), h.env.size() * 4))) return rc;
+    if (s->compact && !peer && h.n_nodes) {
+        // the closest-hit kernel reads the compact nodes and the guards; the 128-byte nodes they are made from go
+        if ((rc = s->qnodes.ensure(h.n_nodes * (RT_QNODE_FLOAT4S * 16) + 128))) return rc;
+        if ((rc = s->guards.ensure(h.n_prims * (RT_GUARD_FLOAT4S * 16) + 128))) return rc;
+        hipLaunchKernelGGL(compact_nodes_kernel, dim3(blocks_for(h.n_nodes)), dim3(kBlock), 0, 0, (const float4 *)s->nodes.p,
+                           (uint32_t)h.n_nodes, (float4 *)s->qnodes.p, (float4 *)s->guards.p);
+        RT_HIP(hipGetLastError());
+        RT_HIP(hipDeviceSynchronize());
+        s->nodes.release();
+    }
+    for (const DevBuf *b : {&s->nodes, &s->qnodes, &s->guards, &s->prims, &s->shade_records, &s->materials, &s->env})
+        s->device_bytes += b->bytes;
     RtSceneView &v = s->view;
     v.nodes = s->nodes.p;
+    v.qnodes = s->qnodes.p;
+    v.guards = s->guards.p;
     v.prims = s->prims.p;
     v.shade_records = s->shade_records.p;
     v.materials = s->materials.p;
@@ -1100,10 +1196,11 @@ int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info) {
     info->n_wide_nodes = h.n_nodes;
     info->n_binary_nodes = h.n_binary_nodes;
     info->wide_depth = h.wide_depth;
-    info->node_bytes = RT_NODE_FLOAT4S * 16;
+    // what a scene made from this build holds on the device: compact nodes, leaf guards, records, materials, environment
+    info->node_bytes = RT_QNODE_FLOAT4S * 16;
     info->primitive_bytes = RT_PRIM_FLOAT4S * 16;
-    info->device_bytes = (h.nodes.size() + h.prims.size() + h.shade_records.size() + h.env.size()) * 4 +
-                         h.materials.size() * sizeof(RtDevMaterial);
+    info->device_bytes = h.n_nodes * (RT_QNODE_FLOAT4S * 16) + h.n_prims * (RT_GUARD_FLOAT4S * 16) +
+                         (h.prims.size() + h.shade_records.size() + h.env.size()) * 4 + h.materials.size() * sizeof(RtDevMaterial);
     info->builder = RT_BUILD_EXACT;
     for (int k = 0; k < 3; k++) info->bounds_min[k] = h.root_lo[k], info->bounds_max[k] = h.root_hi[k];
     return RT_OK;
@@ -1126,7 +1223,7 @@ int rt_scene_info(const RtScene *s, RtSceneInfo *info) {
     info->n_wide_nodes = s->host.n_nodes;
     info->n_binary_nodes = s->host.n_binary_nodes;
     info->wide_depth = s->host.wide_depth;
-    info->node_bytes = RT_NODE_FLOAT4S * 16;
+    info->node_bytes = (s->compact ? RT_QNODE_FLOAT4S : RT_NODE_FLOAT4S) * 16;
     info->primitive_bytes = RT_PRIM_FLOAT4S * 16;
     info->device_bytes = s->device_bytes;
     info->builder = (uint32_t)s->builder;
@@ -1282,9 +1379,10 @@ int rt_closest_hit_batch_noalloc_device(RtScene *s, const float *d_org_dir, floa
     const uint32_t m = (uint32_t)n;
     RT_HIP(hipMemsetAsync(head, 0, 256, stream));  // the array keeps the last call's contents
     hipLaunchKernelGGL(pack_rays_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream, d_org_dir, m, ro, rd);
-    hipLaunchKernelGGL(extend_kernel<false>, dim3(blocks), dim3(kBlock), 0, stream, s->view, (const float4 *)ro,
-                       (const float4 *)rd, (const uint32_t *)nullptr, m, t_min, t_max, hit, ovf, head,
-                       (unsigned long long *)nullptr);
+    auto kernel = s->compact ? extend_kernel<false, true> : extend_kernel<false, false>;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0,
+                       stream, s->view, (const float4 *)ro, (const float4 *)rd, (const uint32_t *)nullptr, m, t_min, t_max,
+                       hit, ovf, head, (unsigned long long *)nullptr);
     hipLaunchKernelGGL(unpack_hits_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream, s->view, (const float2 *)hit,
                        (const float4 *)ro, (const float4 *)rd, m, d_id, d_t, d_normal, d_point);
     RT_HIP(hipGetLastError());

@@ -32,7 +32,7 @@ def test_tree_matches_oracle(pkg, oracle, name):
     mn, mx = ora.bounds()
     assert np.array_equal(np.array(info.bounds_min[:], np.float32), mn)
     assert np.array_equal(np.array(info.bounds_max[:], np.float32), mx)
-    assert info.node_bytes == 128 and info.primitive_bytes == 48
+    assert info.node_bytes == 64 and info.primitive_bytes == 48
     assert 1 <= info.n_wide_nodes <= max(1, info.n_binary_nodes)
 
 

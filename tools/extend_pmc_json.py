@@ -19,7 +19,7 @@ from srchash import kernel_source_hash  # noqa: E402
 
 d = sys.argv[1]
 out_path = sys.argv[2]
-KERNELS = {"extend": "extend_kernel<false>", "extend_pool": "extend_pool_kernel<false>", "shade": "shade_kernel"}
+KERNELS = {"extend": "extend_kernel<false", "extend_pool": "extend_pool_kernel<false>", "shade": "shade_kernel"}
 
 
 def rows(pattern):
