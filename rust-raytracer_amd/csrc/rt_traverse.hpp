@@ -595,37 +595,37 @@ RT_DEV bool traversal_qnode_step(const RtSceneView &sc, Traversal &tr, Stack &st
 
 // tr.entry is a leaf reached through compact boxes: its guard box -- the box the reference tests last before these
 // primitives -- is tested first, by the reference's formula, and the primitives count only if the ray gets through it.
+// Guard and records come from the leaf's block, one 128-byte line.
 template <bool COUNT>
 RT_DEV void traversal_guarded_leaf_step(const RtSceneView &sc, Traversal &tr, float t_min, float t_max, uint32_t *tests) {
-    const float4 *__restrict__ prims = (const float4 *)sc.prims;
     const uint32_t entry = tr.entry;
-    const int32_t first = (int32_t)(entry & RT_LEAF_FIRST_MASK);
     const int32_t count = (int32_t)((entry >> 28) & 7u) + 1;
-    const float4 *g = (const float4 *)sc.guards + (size_t)first * RT_GUARD_FLOAT4S;
-    const float4 *r = prims + (size_t)first * RT_PRIM_FLOAT4S;
+    const float4 *__restrict__ b = (const float4 *)sc.leaves + (size_t)(entry & RT_LEAF_FIRST_MASK) * RT_LEAF_BLOCK_FLOAT4S;
     const bool two = count > 1;
-    const float4 g0 = g[0], g1 = g[1];
-    float4 a0 = r[0], a1 = r[1], a2 = r[2];
-    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 g0 = b[0], g1 = b[1];
+    float4 a0 = b[2], a1 = b[3], a2 = b[4];
+    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // (not a copy of the first record: that would wait for it)
     float4 b0 = zero, b1 = zero, b2 = zero;
-    if (two) b0 = r[3], b1 = r[4], b2 = r[5];
+    if (two) b0 = b[5], b1 = b[6], b2 = b[7];
     // src/tracer/cube.rs:163-171 on the guard box
     const F3 t0 = (f3(g0.x, g0.y, g0.z) - tr.ray.o) * tr.inv;
     const F3 t1 = (f3(g0.w, g1.x, g1.y) - tr.ray.o) * tr.inv;
     const float tn = fmaxf(max3(f3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z))), t_min);
     const float tf = fminf(min3(f3(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z))), tr.best.t);
     const bool open = tn <= tf;
+    const int32_t first = (int32_t)__float_as_uint(g1.z);
     if (COUNT) (*tests) += open ? (uint32_t)count : 0u;
-    Best b = tr.best;
-    test_record(a0, a1, a2, first, tr.ray, tr.inv, t_min, t_max, b);
-    if (two) test_record(b0, b1, b2, first + 1, tr.ray, tr.inv, t_min, t_max, b);
-    for (int32_t k = 2; k < count; k++) {
-        const float4 *q = prims + (size_t)(first + k) * RT_PRIM_FLOAT4S;
-        test_record(q[0], q[1], q[2], first + k, tr.ray, tr.inv, t_min, t_max, b);
+    Best best = tr.best;
+    test_record(a0, a1, a2, first, tr.ray, tr.inv, t_min, t_max, best);
+    if (two) test_record(b0, b1, b2, first + 1, tr.ray, tr.inv, t_min, t_max, best);
+    for (int32_t k = 2; k < count; k += 2) {  // (no builder makes such leaves today)
+        const float4 *q = b + (size_t)(k >> 1) * RT_LEAF_BLOCK_FLOAT4S;
+        test_record(q[2], q[3], q[4], first + k, tr.ray, tr.inv, t_min, t_max, best);
+        if (k + 1 < count) test_record(q[5], q[6], q[7], first + k + 1, tr.ray, tr.inv, t_min, t_max, best);
     }
-    tr.best.t = open ? b.t : tr.best.t;
-    tr.best.index = open ? b.index : tr.best.index;
-    tr.best.ties = open ? b.ties : tr.best.ties;
+    tr.best.t = open ? best.t : tr.best.t;
+    tr.best.index = open ? best.index : tr.best.index;
+    tr.best.ties = open ? best.ties : tr.best.ties;
 }
 
 }  // namespace rtd

@@ -31,18 +31,23 @@
 #define RT_LEAF_MAX_PRIMS 7u
 #define RT_LEAF_FIRST_MASK 0x0FFFFFFFu
 
-// ---- compact wide node (the form the closest-hit kernel reads) -------------------------------------------
-// 64 B = 4 x float4: the four child boxes on a 256-step grid of the node's own box.  Plane k of axis a lies at
-// origin[a] + k * step[a], step a power of two; a child's box is rounded OUTWARD to the grid, so it contains the
-// exact box.  A compact box only steers the traversal (any box that contains the exact one does, see rt_traverse.hpp);
-// the exact box of a leaf slot is kept beside it as that leaf's guard (32 B, indexed by the leaf's first primitive)
-// and tested when the leaf is reached.
+// ---- compact wide node and leaf block (the forms the closest-hit kernel reads) -----------------------------
+// Compact node, 64 B = 4 x float4: the four child boxes on a 256-step grid of the node's own box.  Plane k of axis a
+// lies at origin[a] + k * step[a], step a power of two; a child's box is rounded OUTWARD to the grid, so it contains
+// the exact box.  A compact box only steers the traversal (any box that contains the exact one does, see
+// rt_traverse.hpp); the exact box of a leaf slot is kept in the leaf's block as its guard and tested when the leaf is
+// reached.
 // float4 0 : origin.x, origin.y, origin.z, step.x
 // float4 1 : step.y, step.z, lo.x[4 bytes, child c in byte c], lo.y[4]
 // float4 2 : lo.z[4], hi.x[4], hi.y[4], hi.z[4]
-// float4 3 : child words (an inner child's word is the index of its compact node)
+// float4 3 : child words: an inner child's word is the index of its compact node; a leaf's word has bit 31 set,
+//            bits 28..30 = primitive count - 1, bits 0..27 = index of its first leaf block
+// Leaf block, 128 B = 8 x float4 (one line): up to two primitives of a leaf; a leaf with more takes consecutive blocks.
+// float4 0 : guard lo.x, lo.y, lo.z, hi.x
+// float4 1 : guard hi.y, hi.z, visit rank of the block's first primitive (bits), primitives in this block (bits)
+// float4 2..4, 5..7 : the primitive records
 #define RT_QNODE_FLOAT4S 4
-#define RT_GUARD_FLOAT4S 2
+#define RT_LEAF_BLOCK_FLOAT4S 8
 
 // ---- primitive record ------------------------------------------------------
 // word 10 = meta, word 11 = primitive id (scene declaration order)
@@ -89,9 +94,9 @@ struct RtDevCamera {
 
 // What a kernel needs to see of a scene (passed by value).
 struct RtSceneView {
-    const void *nodes;       // float4[n_nodes * 8]
+    const void *nodes;       // float4[n_nodes * 8]; a scene holds either these and prims, or qnodes and leaves
     const void *qnodes;      // float4[n_nodes * 4]: the compact nodes
-    const void *guards;      // float4[n_prims * 2]: lo.xyz hi.x | hi.yz - -, at the first primitive of each leaf slot
+    const void *leaves;      // float4[n_blocks * 8]: the leaf blocks
     const void *prims;       // float4[n_prims * 3]
     const void *shade_records; // float4[n_prims * 6]: the primitive's record and its three vertex normals side by side,
                                // one 96-byte gather for the stage that completes a hit

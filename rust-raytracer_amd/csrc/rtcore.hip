@@ -33,6 +33,7 @@
 #include "rt_traverse.hpp"
 #include "rt_pool.hpp"
 #include "scene_build.hpp"
+#include "compact.hpp"
 #include "gpu_build.hpp"
 
 using namespace rtd;
@@ -245,11 +246,14 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
             // straddle two lines).  Lanes at the same node or in the same line share a look-up.
             uint32_t lk = 0;
             if (run_node && n_node) lk += COMPACT ? 4u * wave_distinct(at_node, tr.entry >> 1) : 7u * wave_distinct(at_node, tr.entry);
-            if (run_leaf && n_leaf) {
+            if (COMPACT && run_leaf && n_leaf) {  // one block = one line: two loads for the guard, three per record
+                const bool two = ((tr.entry >> 28) & 7u) != 0u;
+                lk += 5u * wave_distinct(at_leaf, tr.entry & RT_LEAF_FIRST_MASK) + 3u * wave_distinct(at_leaf && two, tr.entry & RT_LEAF_FIRST_MASK);
+            }
+            if (!COMPACT && run_leaf && n_leaf) {
                 const uint32_t byte0 = (tr.entry & RT_LEAF_FIRST_MASK) * (RT_PRIM_FLOAT4S * 16u);
                 const bool two = ((tr.entry >> 28) & 7u) != 0u;
                 for (uint32_t k = 0; k < 6u; k++) lk += wave_distinct(at_leaf && (k < 3u || two), (byte0 + 16u * k) >> 7);
-                if (COMPACT) lk += 2u * wave_distinct(at_leaf, (tr.entry & RT_LEAF_FIRST_MASK) >> 2);  // the 32-byte guard
             }
             lookups += lk;
         }
@@ -280,76 +284,6 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
             for (int k = 0; k < 8; k++) atomicAdd(&counters[2 + k], dbg[k]);
             atomicAdd(&counters[14], lookups);
         }
-    }
-}
-
-// The compact nodes and the leaf guards, made from the 128-byte nodes (one thread per node; rt_types.h has the layout).
-// Per axis the grid starts at the lowest plane of the node's children and its step is the smallest power of two with
-// 255 steps reaching the highest; a child's low planes are rounded down to the grid and its high planes up.  An axis
-// on which some child's box is not finite (a NaN or infinite vertex) or which no such grid spans gets an infinite step:
-// the traversal then ignores that axis for every child of the node.
-__global__ void __launch_bounds__(kBlock) compact_nodes_kernel(const float4 *__restrict__ nodes, uint32_t n_nodes,
-                                                               float4 *__restrict__ qnodes, float4 *__restrict__ guards) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_nodes) return;
-    const float4 *nd = nodes + (size_t)i * RT_NODE_FLOAT4S;
-    float4 plane[6];
-    for (int k = 0; k < 6; k++) plane[k] = nd[k];
-    const float4 cwf = nd[6];
-    const uint32_t cw[4] = {__float_as_uint(cwf.x), __float_as_uint(cwf.y), __float_as_uint(cwf.z), __float_as_uint(cwf.w)};
-    float origin[3], step[3];
-    uint32_t qlo[3], qhi[3];
-    for (int a = 0; a < 3; a++) {
-        const float lo[4] = {plane[a].x, plane[a].y, plane[a].z, plane[a].w};
-        const float hi[4] = {plane[a + 3].x, plane[a + 3].y, plane[a + 3].z, plane[a + 3].w};
-        double mn = 1e300, mx = -1e300;
-        bool open = false, any = false;
-        for (int c = 0; c < 4; c++) {
-            if (cw[c] == RT_CHILD_NONE) continue;
-            any = true;
-            if (!(fabsf(lo[c]) <= 3.0e38f) || !(fabsf(hi[c]) <= 3.0e38f) || !(lo[c] <= hi[c]))
-                open = true;
-            else
-                mn = fmin(mn, (double)lo[c]), mx = fmax(mx, (double)hi[c]);
-        }
-        origin[a] = 0.0f, step[a] = __int_as_float(0x7f800000), qlo[a] = 0u, qhi[a] = 0u;
-        if (!any || open) continue;
-        const double ext = mx - mn;
-        double s = 0x1p-100;
-        if (ext > 0.0) {
-            int e;
-            (void)frexp(ext / 255.0, &e);  // ext / 255 = f * 2^e with f in [0.5, 1)
-            s = ldexp(1.0, e - 1);
-            if (s < 0x1p-100) s = 0x1p-100;
-            while (s * 255.0 < ext) s *= 2.0;
-        }
-        if (s > 0x1p100) continue;
-        origin[a] = (float)mn;
-        step[a] = (float)s;
-        for (int c = 0; c < 4; c++) {
-            if (cw[c] == RT_CHILD_NONE) continue;
-            double l = floor(((double)lo[c] - mn) / s), h = ceil(((double)hi[c] - mn) / s);
-            l = fmin(fmax(l, 0.0), 255.0), h = fmin(fmax(h, 0.0), 255.0);
-            qlo[a] |= (uint32_t)l << (8 * c);
-            qhi[a] |= (uint32_t)h << (8 * c);
-        }
-    }
-    float4 *q = qnodes + (size_t)i * RT_QNODE_FLOAT4S;
-    q[0] = make_float4(origin[0], origin[1], origin[2], step[0]);
-    q[1] = make_float4(step[1], step[2], __uint_as_float(qlo[0]), __uint_as_float(qlo[1]));
-    q[2] = make_float4(__uint_as_float(qlo[2]), __uint_as_float(qhi[0]), __uint_as_float(qhi[1]), __uint_as_float(qhi[2]));
-    q[3] = cwf;
-    for (int c = 0; c < 4; c++) {
-        if (cw[c] == RT_CHILD_NONE || !(cw[c] & RT_CHILD_LEAF)) continue;
-        const float l[3] = {c == 0 ? plane[0].x : c == 1 ? plane[0].y : c == 2 ? plane[0].z : plane[0].w,
-                            c == 0 ? plane[1].x : c == 1 ? plane[1].y : c == 2 ? plane[1].z : plane[1].w,
-                            c == 0 ? plane[2].x : c == 1 ? plane[2].y : c == 2 ? plane[2].z : plane[2].w};
-        const float h[3] = {c == 0 ? plane[3].x : c == 1 ? plane[3].y : c == 2 ? plane[3].z : plane[3].w,
-                            c == 0 ? plane[4].x : c == 1 ? plane[4].y : c == 2 ? plane[4].z : plane[4].w,
-                            c == 0 ? plane[5].x : c == 1 ? plane[5].y : c == 2 ? plane[5].z : plane[5].w};
-        float4 *g = guards + (size_t)(cw[c] & RT_LEAF_FIRST_MASK) * RT_GUARD_FLOAT4S;
-        g[0] = make_float4(l[0], l[1], l[2], h[0]);
-        g[1] = make_float4(h[1], h[2], 0.0f, 0.0f);
     }
 }
 
@@ -713,7 +647,7 @@ struct RtScene {
     int device = 0;
     int n_cus = 256;
     rtcore::HostScene host;  // metadata only after upload (big arrays are released)
-    DevBuf nodes, qnodes, guards, prims, shade_records, materials, env;
+    DevBuf nodes, qnodes, leaves, prims, shade_records, materials, env;
     bool compact = false;  // the closest-hit kernel walks the compact nodes (RTCORE_NODES=compact)
     RtSceneView view{};
     // work buffers
@@ -1062,7 +996,7 @@ static int upload_scene(const rtcore::HostScene &h, rtcore::DeviceBuild *dev, co
             RT_HIP(hipMemcpyPeer(b.p, s->device, from.p, peer->device, from.bytes));
             return RT_OK;
         };
-        if ((rc = copy(s->nodes, peer->nodes)) || (rc = copy(s->qnodes, peer->qnodes)) || (rc = copy(s->guards, peer->guards)) ||
+        if ((rc = copy(s->nodes, peer->nodes)) || (rc = copy(s->qnodes, peer->qnodes)) || (rc = copy(s->leaves, peer->leaves)) ||
             (rc = copy(s->prims, peer->prims)) || (rc = copy(s->shade_records, peer->shade_records)))
             return rc;
     } else {
@@ -1072,22 +1006,30 @@ static int upload_scene(const rtcore::HostScene &h, rtcore::DeviceBuild *dev, co
     }
     if ((rc = upload(s->materials, h.materials.data(), h.materials.size() * sizeof(RtDevMaterial)))) return rc;
     if ((rc = upload(s->env, h.env.data(), h.env.size() * 4))) return rc;
-    if (s->compact && !peer && h.n_nodes) {
-        // the closest-hit kernel reads the compact nodes and the guards; the 128-byte nodes they are made from go
-        if ((rc = s->qnodes.ensure(h.n_nodes * (RT_QNODE_FLOAT4S * 16) + 128))) return rc;
-        if ((rc = s->guards.ensure(h.n_prims * (RT_GUARD_FLOAT4S * 16) + 128))) return rc;
-        hipLaunchKernelGGL(compact_nodes_kernel, dim3(blocks_for(h.n_nodes)), dim3(kBlock), 0, 0, (const float4 *)s->nodes.p,
-                           (uint32_t)h.n_nodes, (float4 *)s->qnodes.p, (float4 *)s->guards.p);
-        RT_HIP(hipGetLastError());
-        RT_HIP(hipDeviceSynchronize());
-        s->nodes.release();
+    if (s->compact && !peer) {
+        // the closest-hit kernel reads compact nodes and leaf blocks; the 128-byte nodes and the primitive records they
+        // are made from go (a tree whose leaf blocks a child word cannot address keeps the 128-byte nodes)
+        rtcore::CompactTree ct;
+        std::string err;
+        rc = rtcore::compact_tree(s->nodes.p, h.n_nodes, s->prims.p, h.n_prims, ct, err);
+        if (rc == RT_ERR_INVALID_ARGUMENT) {
+            s->compact = false;
+            s->extend_blocks = resident_extend_blocks(s->n_cus, false);
+        } else if (rc != RT_OK) {
+            return fail(rc, err);
+        } else {
+            s->qnodes.p = ct.qnodes, s->qnodes.bytes = ct.qnodes_bytes;
+            s->leaves.p = ct.leaves, s->leaves.bytes = ct.leaves_bytes;
+            s->nodes.release();
+            s->prims.release();
+        }
     }
-    for (const DevBuf *b : {&s->nodes, &s->qnodes, &s->guards, &s->prims, &s->shade_records, &s->materials, &s->env})
+    for (const DevBuf *b : {&s->nodes, &s->qnodes, &s->leaves, &s->prims, &s->shade_records, &s->materials, &s->env})
         s->device_bytes += b->bytes;
     RtSceneView &v = s->view;
     v.nodes = s->nodes.p;
     v.qnodes = s->qnodes.p;
-    v.guards = s->guards.p;
+    v.leaves = s->leaves.p;
     v.prims = s->prims.p;
     v.shade_records = s->shade_records.p;
     v.materials = s->materials.p;
@@ -1196,11 +1138,19 @@ int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info) {
     info->n_wide_nodes = h.n_nodes;
     info->n_binary_nodes = h.n_binary_nodes;
     info->wide_depth = h.wide_depth;
-    // what a scene made from this build holds on the device: compact nodes, leaf guards, records, materials, environment
+    // what a scene made from this build holds on the device: compact nodes, leaf blocks, the records the shading
+    // stage reads, materials, environment
+    uint64_t n_blocks = 0;
+    for (size_t nd = 0; nd < h.n_nodes; nd++) {
+        uint32_t w[4];
+        std::memcpy(w, &h.nodes[nd * 32 + 24], 16);
+        for (int c = 0; c < 4; c++)
+            if (w[c] != RT_CHILD_NONE && (w[c] & RT_CHILD_LEAF)) n_blocks += (((w[c] >> 28) & 7u) + 2u) >> 1;
+    }
     info->node_bytes = RT_QNODE_FLOAT4S * 16;
     info->primitive_bytes = RT_PRIM_FLOAT4S * 16;
-    info->device_bytes = h.n_nodes * (RT_QNODE_FLOAT4S * 16) + h.n_prims * (RT_GUARD_FLOAT4S * 16) +
-                         (h.prims.size() + h.shade_records.size() + h.env.size()) * 4 + h.materials.size() * sizeof(RtDevMaterial);
+    info->device_bytes = h.n_nodes * (RT_QNODE_FLOAT4S * 16) + n_blocks * (RT_LEAF_BLOCK_FLOAT4S * 16) +
+                         (h.shade_records.size() + h.env.size()) * 4 + h.materials.size() * sizeof(RtDevMaterial);
     info->builder = RT_BUILD_EXACT;
     for (int k = 0; k < 3; k++) info->bounds_min[k] = h.root_lo[k], info->bounds_max[k] = h.root_hi[k];
     return RT_OK;
