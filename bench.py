@@ -11,19 +11,21 @@ Prints ONE JSON line on rank 0:
 
   value        Mrays/s of the whole job: Bvh::hit invocations (primary rays + every continued
                bounce) of all ranks / max-over-ranks wall time of the K steps
-  roofline     closest-hit ("extend") kernel.  Its loads are per-lane 16-byte gathers (a tree node = seven loads from one
-               128-byte line per lane), and what they saturate is the CU's vector memory path: address unit (TA),
-               L1 tags (TCP) and data return (TD), which take one cache-line access per clock and CU.
-                 frac = TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles)          [bound "l1"]
-               from the rocprofv3 counter profile of this same configuration under profiles/, used only while its
-               stamp (hash of the kernel sources, bench arguments) matches this run; TA / TD busy fractions beside it.
-               Without a matching profile: the line look-ups of the node and primitive fetches, counted live by the
-               instrumented kernel (a lower bound of the accesses).  Also reported, not used as the fraction:
-               the vector ALU (VALU busy x active lanes / 64 per instruction: the unit is busy ~0.9 of the time at
-               about half its lanes), the HBM side (FETCH_SIZE x the factor calibrated on a one-line-per-lane gather,
-               / launch time, / 8 TB/s) and the algorithmic bytes per ray (node visits x 128 B + primitive tests x 48 B
-               + 40 B, counted live at the timed resolution), most of which the caches serve.  Launch durations are
-               HIP events on the launch stream.
+  roofline     closest-hit ("extend") kernel, from the rocprofv3 counter profile of this same configuration under
+               profiles/, used only while its stamp (hash of the kernel sources, bench arguments) matches this run.  Two
+               units can bound it and both are reported; `bound` names the busier one:
+                 "valu"  the vector ALU.  frac = VALU busy (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles, capped at 1) x active
+                         lanes per instruction / 64 = useful lane-operations over the peak of one wave64 instruction per
+                         4 cycles and SIMD.  Over the compact 64-byte nodes the unit is busy all the time at a little over
+                         half its lanes: the lanes of a wave are at different depths of different rays.
+                 "l1"    the CU's vector memory path (address unit TA, L1 tags TCP, data return TD), one cache-line access
+                         per clock and CU: frac = TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles), TA / TD busy beside it.  This
+                         bounds the kernel over the 128-byte nodes (RTCORE_NODES=wide: seven loads per node and lane).
+               Without a matching profile: the line look-ups of the node and leaf fetches, counted live by the
+               instrumented kernel (a lower bound of the L1's accesses).  Also reported: the HBM side (FETCH_SIZE x the
+               factor calibrated on a one-line-per-lane gather, / launch time, / 8 TB/s) and the algorithmic bytes per ray
+               (node visits x 64 B + leaf visits x 32 B of guard box + primitive tests x 48 B + 40 B, counted live at the
+               timed resolution), most of which the caches serve.  Launch durations are HIP events on the launch stream.
   cpu_baseline the CPU oracle (a restatement of the reference's renderer, not the Rust binary)
                on a bounded sample of the same workload: same scene, samples and bounces at a
                reduced resolution, on this box's host cores (N=1 only)
@@ -298,15 +300,14 @@ def main():
             "prim_tests_per_ray": round(tests_per_ray, 2),
         }
         if extend_s > 0 and lookups_per_ray > 0:
-            # The vector L1 looks up one 128-byte line per clock and CU (tools/ubench/node_fetch.hip: 7 loads per lane
-            # from a line of its own, L2-resident table: 6.5 clocks per node and CU), and a wave's load instruction
-            # costs one look-up per DIFFERENT line among its lanes.  Look-ups of the node and primitive fetches are
-            # counted live by the instrumented kernel; ray loads, hit stores and stack overflow are not included.
+            # The vector L1 looks up one 128-byte line per clock and CU (tools/ubench/node_fetch.hip), and a wave's load
+            # instruction costs one look-up per DIFFERENT line among its lanes.  Look-ups of the node and leaf fetches
+            # are counted live by the instrumented kernel; ray loads, hit stores and stack overflow are not included.
             peak = N_CU * MAX_CLOCK_GHZ
             achieved = st.rays * lookups_per_ray / extend_s / 1e9
             roof["l1_lookup"] = {"achieved_G_per_s": round(achieved, 1), "peak_G_per_s": round(peak, 1),
                                  "frac": round(achieved / peak, 4), "lookups_per_ray": round(lookups_per_ray, 1),
-                                 "note": "one line look-up per clock and CU; counted for node and primitive fetches only"}
+                                 "note": "one line look-up per clock and CU; counted for node and leaf fetches only"}
         if prof is not None:
             e = prof["extend"]
             clock = e.get("clock_GHz_under_profile") or MAX_CLOCK_GHZ
@@ -314,7 +315,9 @@ def main():
             cu_cycles = prof_launch_s * clock * 1e9 * N_CU  # CU-cycles of one launch
             # vector ALU: G lane-op/s at one wave64 instruction per 4 SIMD cycles on every SIMD ("VALU busy = 1, all lanes active")
             valu_peak = N_SIMD * 64 / 4.0 * clock
-            valu_frac = e["valu_busy_fraction"] * e["valu_lane_utilisation"]
+            # (the busy figure is rocprof's VALUBusy; it comes out a little above 1 when the unit never idles, because
+            # some instructions issue in fewer than four cycles: capped)
+            valu_frac = min(1.0, e["valu_busy_fraction"]) * e["valu_lane_utilisation"]
             factor, factor_note = fetch_factor()
             hbm_bytes = e["hbm_bytes_per_launch_raw"] * factor
             valu = {"achieved_G_lane_op_per_s": round(valu_frac * valu_peak, 1), "peak_G_lane_op_per_s": round(valu_peak, 1),
@@ -331,21 +334,24 @@ def main():
                                      "note": "counters from separate rocprofv3 --pmc runs of this configuration (one run per counter group), "
                                              "not from this run"}})
             acc = e.get("TCP_TOTAL_CACHE_ACCESSES_sum_per_launch")
+            l1 = None
             if acc:
-                # The kernel's loads are per-lane 16-byte gathers: what they load is the CU's vector memory path
-                # (address unit TA -> L1 tags TCP -> data return TD), which takes one cache-line access per clock.
-                peak = N_CU * clock
-                roof.update({"bound": "l1", "unit": "G line accesses/s",
-                             "achieved": round(acc / prof_launch_s / 1e9, 1), "peak": round(peak, 1),
-                             "frac": round(acc / cu_cycles, 4),
-                             "l1": {"accesses_per_launch": int(acc),
-                                    "ta_busy": round(e.get("TA_TA_BUSY_sum_per_launch", 0.0) / cu_cycles, 4),
-                                    "td_busy": round(e.get("TD_TD_BUSY_sum_per_launch", 0.0) / cu_cycles, 4),
-                                    "ta_stalled_by_l1": round(e.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum_per_launch", 0.0) / cu_cycles, 4),
-                                    "requests_to_l2_per_launch": int(e.get("TCP_TCC_READ_REQ_sum_per_launch", 0)),
-                                    "note": "TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles): one line access per clock and CU is what "
-                                            "tools/ubench/node_fetch.hip reaches with this load shape; TA / TD busy = the "
-                                            "address and data-return units' busy cycles / cycles"}})
+                # per-lane 16-byte gathers load the CU's vector memory path (address unit TA -> L1 tags TCP -> data
+                # return TD), which takes one cache-line access per clock
+                l1 = {"achieved_G_line_accesses_per_s": round(acc / prof_launch_s / 1e9, 1), "peak_G_line_accesses_per_s": round(N_CU * clock, 1),
+                      "frac": round(acc / cu_cycles, 4), "accesses_per_launch": int(acc),
+                      "ta_busy": round(e.get("TA_TA_BUSY_sum_per_launch", 0.0) / cu_cycles, 4),
+                      "td_busy": round(e.get("TD_TD_BUSY_sum_per_launch", 0.0) / cu_cycles, 4),
+                      "td_waiting_for_l1": round(e.get("TD_TC_STALL_sum_per_launch", 0.0) / cu_cycles, 4),
+                      "ta_stalled_by_l1": round(e.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum_per_launch", 0.0) / cu_cycles, 4),
+                      "requests_to_l2_per_launch": int(e.get("TCP_TCC_READ_REQ_sum_per_launch", 0)),
+                      "note": "TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles): one line access per clock and CU is what "
+                              "tools/ubench/node_fetch.hip reaches with this load shape; TA / TD busy = the address and "
+                              "data-return units' busy cycles / cycles (TD busy includes its waiting for the L1)"}
+                roof["l1"] = l1
+            if l1 is not None and l1["frac"] > min(1.0, e["valu_busy_fraction"]):
+                roof.update({"bound": "l1", "unit": "G line accesses/s", "achieved": l1["achieved_G_line_accesses_per_s"],
+                             "peak": l1["peak_G_line_accesses_per_s"], "frac": l1["frac"]})
             else:
                 roof.update({"bound": "valu", "unit": "G lane-op/s", "achieved": valu["achieved_G_lane_op_per_s"],
                              "peak": valu["peak_G_lane_op_per_s"], "frac": valu["frac"]})
