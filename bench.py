@@ -72,6 +72,10 @@ def build_workload(pkg, args):
 
 def config_key(args):
     """Names the timed configuration; a counter profile is only used for the configuration it was taken on."""
+    return _config_key(args) + (" nodes=wide" if os.environ.get("RTCORE_NODES") == "wide" else "")
+
+
+def _config_key(args):
     if args.workload == "closest_hit":
         return "closest_hit tris=%d rays=%d%s" % (args.tris, args.rays, " builder=device" if args.builder == "device" else "")
     tris = args.tris if args.workload == "mesh" else 0

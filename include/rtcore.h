@@ -191,7 +191,7 @@ typedef struct RtSceneInfo {
     uint64_t n_wide_nodes;
     uint64_t n_binary_nodes; /* nodes of the reference-shaped tree the wide tree was collapsed from */
     uint32_t wide_depth;
-    uint32_t node_bytes;      /* bytes of one wide node */
+    uint32_t node_bytes;      /* bytes of one wide node as the closest-hit kernel reads it (64: compact form; 128 with RTCORE_NODES=wide) */
     uint32_t primitive_bytes; /* bytes of one primitive record */
     uint32_t builder;         /* RtBuilder that made the tree (RT_BUILD_EXACT or RT_BUILD_DEVICE) */
     uint64_t device_bytes; /* HBM held by the scene */

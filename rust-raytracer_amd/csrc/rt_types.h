@@ -3,10 +3,12 @@
 // Everything the kernels read lives in HBM as arrays of 16-byte words so that a
 // lane fetches whole records with global_load_dwordx4:
 //
-//   wide node   128 B = 8 x float4   four child boxes in SoA form + four child words
-//   primitive    48 B = 3 x float4   one record per primitive, all types
-//   normals      48 B = 3 x float4   vertex normals of a triangle (same index as its record)
-//   material     32 B = 2 x float4
+//   wide node    128 B = 8 x float4   four exact child boxes in SoA form + four child words (what the builds make)
+//   primitive     48 B = 3 x float4   one record per primitive, all types
+//   compact node  64 B = 4 x float4   the four child boxes on a 256-step grid + four child words   } what the closest-hit
+//   leaf block   128 B = 8 x float4   a leaf's exact guard box + its (up to two) primitive records } kernel reads
+//   shade record  96 B = 6 x float4   a primitive's record + the vertex normals of a triangle (same index as its record)
+//   material      32 B = 2 x float4
 //
 // Primitives are stored in the order in which the reference's recursive traversal
 // (right child first, src/tracer/bvh.rs:148-155) reaches its leaves, so the array

@@ -242,8 +242,9 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         }
         if (COUNT) {
             // What the step asks of the vector L1: every load instruction looks up each DIFFERENT 128-byte line its
-            // lanes address (a node is seven loads from one line; a primitive record is three loads, 48 bytes that may
-            // straddle two lines).  Lanes at the same node or in the same line share a look-up.
+            // lanes address.  A compact node is four loads from half a line, a leaf block five or eight loads from one
+            // line; a 128-byte node is seven loads from one line and a primitive record three loads, 48 bytes that may
+            // straddle two lines.  Lanes at the same node or in the same line share a look-up.
             uint32_t lk = 0;
             if (run_node && n_node) lk += COMPACT ? 4u * wave_distinct(at_node, tr.entry >> 1) : 7u * wave_distinct(at_node, tr.entry);
             if (COMPACT && run_leaf && n_leaf) {  // one block = one line: two loads for the guard, three per record
