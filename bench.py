@@ -77,7 +77,8 @@ def config_key(args):
 
 def _config_key(args):
     if args.workload == "closest_hit":
-        return "closest_hit tris=%d rays=%d%s" % (args.tris, args.rays, " builder=device" if args.builder == "device" else "")
+        return "closest_hit tris=%d rays=%d%s%s" % (args.tris, args.rays, " builder=device" if args.builder == "device" else "",
+                                                     "" if args.inflate == 1.5 else " inflate=%g" % args.inflate)
     tris = args.tris if args.workload == "mesh" else 0
     return "%s tris=%d %dx%d spp=%d bounces=%d batch=%d%s" % (args.workload, tris, args.width, args.height, args.spp,
                                                              args.bounces, args.batch_paths,
@@ -125,6 +126,9 @@ def main():
     ap.add_argument("--spp", type=int, default=16)
     ap.add_argument("--bounces", type=int, default=8)
     ap.add_argument("--rays", type=int, default=100_000_000, help="closest_hit workload: rays per step")
+    ap.add_argument("--inflate", type=float, default=1.5,
+                    help="closest_hit workload: origins are uniform in the scene's box scaled by this about its centre "
+                         "(1.5 = the configuration's definition, many rays miss the room; 0.7 = every ray starts among the meshes)")
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--builder", default="exact", choices=["exact", "device"],
                     help="exact: the reference's tree, built on the host (default); device: the opt-in build on the GPU")
@@ -187,7 +191,7 @@ def main():
         mn, mx = np.array(info.bounds_min[:]), np.array(info.bounds_max[:])
         g = torch.Generator(device="cuda")
         g.manual_seed(0x5EED + rank)
-        c, h = torch.tensor((mn + mx) / 2, device="cuda"), torch.tensor((mx - mn) / 2 * 1.5, device="cuda")
+        c, h = torch.tensor((mn + mx) / 2, device="cuda"), torch.tensor((mx - mn) / 2 * args.inflate, device="cuda")
         org = c + (torch.rand((n_rays, 3), device="cuda", generator=g) * 2 - 1) * h
         z = torch.rand(n_rays, device="cuda", generator=g) * 2 - 1
         ph = torch.rand(n_rays, device="cuda", generator=g) * (2 * math.pi)
