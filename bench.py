@@ -14,10 +14,13 @@ Prints ONE JSON line on rank 0:
   roofline     closest-hit ("extend") kernel, from the rocprofv3 counter profile of this same configuration under
                profiles/, used only while its stamp (hash of the kernel sources, bench arguments) matches this run.  Two
                units can bound it and both are reported; `bound` names the busier one:
-                 "valu"  the vector ALU.  frac = VALU busy (SQ_ACTIVE_INST_VALU x 4 / SIMD cycles, capped at 1) x active
-                         lanes per instruction / 64 = useful lane-operations over the peak of one wave64 instruction per
-                         4 cycles and SIMD.  Over the compact 64-byte nodes the unit is busy all the time at a little over
-                         half its lanes: the lanes of a wave are at different depths of different rays.
+                 "valu"  the vector ALU, against a MEASURED ceiling (profiles/r03_valu_rate.json: the node step's own
+                         code on register-resident nodes, in-kernel cycle counter, at the kernel's waves per SIMD):
+                         peak = every SIMD issuing vector instructions at the ceiling rate with all 64 lanes useful,
+                         achieved = vector instructions x active lanes per instruction,
+                         frac = issue_frac (ceiling cycles per instruction / the kernel's) x lane utilisation.
+                         Beside it the fraction of the ceiling of a stream with the kernel's share of scalar instructions
+                         (scalar instructions take issue time too) and the share of wave-cycles spent waiting.
                  "l1"    the CU's vector memory path (address unit TA, L1 tags TCP, data return TD), one cache-line access
                          per clock and CU: frac = TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles), TA / TD busy beside it.  This
                          bounds the kernel over the 128-byte nodes (RTCORE_NODES=wide: seven loads per node and lane).
@@ -30,6 +33,11 @@ Prints ONE JSON line on rank 0:
                on a bounded sample of the same workload: same scene, samples and bounces at a
                reduced resolution, on this box's host cores (N=1 only)
   --total-passes P  strong scaling: P passes in all, split round-robin over the ranks ("scaling": "strong")
+
+Launching: under a launcher (torchrun sets WORLD_SIZE / RANK / LOCAL_RANK) this process is one rank.  Without one,
+`python bench.py --gpus N` with N > 1 starts the N ranks itself (one child process per GPU, rendezvous on 127.0.0.1)
+before anything touches the GPU, relays rank 0's line and fails if any rank fails.  Either way the line is only
+printed if the ranks that took part are the `--gpus` that were asked for ("ranks_seen", counted by an all-reduce).
 """
 import argparse
 import glob
@@ -114,6 +122,74 @@ def fetch_factor():
     return 1.0, "uncalibrated (raw FETCH_SIZE x 1 KiB)"
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n, command, env=None, timeout=None):
+    """Runs `command` (a list) as n rank processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set,
+    relays rank 0's stdout (the other ranks' stdout is dropped, every rank's stderr passes through) and returns the
+    exit status: 0 only if every rank ended with 0.  When a rank fails the others are ended (their own PIDs only)."""
+    import subprocess
+
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
+                 "LOCAL_WORLD_SIZE": str(n)})
+    procs = []
+    for r in range(n):
+        e = dict(base)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        procs.append(subprocess.Popen(command, env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+    t_end = None if timeout is None else time.time() + timeout
+    status = 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                sys.stderr.write("bench.py: rank %d ended with status %d; ending the other ranks\n" % (r, rc))
+        if live and (status != 0 or (t_end is not None and time.time() > t_end)):
+            if status == 0:
+                status = 124
+                sys.stderr.write("bench.py: ranks still running after %.0f s; ending them\n" % timeout)
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        if live:
+            time.sleep(0.05)
+    return status
+
+
+def valu_ceiling(waves_per_simd):
+    """The measured vector issue ceiling (profiles/r03_valu_rate.json, made by tools/ubench/valu_rate.hip on MI355X): cycles
+    per vector instruction and SIMD of the node step's instruction mix at `waves_per_simd`; the guide's 2 cycles per
+    wave64 instruction (SIMD-32) when no table is committed."""
+    path = os.path.join(ROOT, "profiles", "r03_valu_rate.json")
+    if os.path.exists(path):
+        t = json.load(open(path))
+        by_w = t["node_step"]["cycles_per_vector_instruction_and_simd_by_waves_per_simd"]
+        w = str(waves_per_simd) if str(waves_per_simd) in by_w else sorted(by_w, key=lambda k: abs(int(k) - waves_per_simd))[0]
+        mix = t["rows"].get("v_fma_f32 + s_and_b64 (2 : 1)", {}).get("cycles_per_instruction_and_simd_by_waves_per_simd", {})
+        return {"cycles_per_vector_instruction": by_w[w], "cycles_per_vector_instruction_2_to_1_scalar": mix.get(w),
+                "source": "profiles/r03_valu_rate.json: node step (rtd::qnode_children_sorted, %d vector instructions) at %s waves per SIMD, "
+                          "in-kernel s_memtime cycles" % (t["node_step"]["loop_instructions"]["vector"], w)}
+    return {"cycles_per_vector_instruction": 2.0, "cycles_per_vector_instruction_2_to_1_scalar": None,
+            "source": "no measured table committed: 2 cycles per wave64 vector instruction (SIMD-32)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +215,20 @@ def main():
     ap.add_argument("--reduce", default="auto", choices=["auto", "torch", "native"],
                     help="how the accumulators are summed at N > 1: torch.distributed (RCCL) or the library's own RCCL reduce")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be at least 1")
+    # one process per GPU; RT_BENCH_BACKEND=gloo lets several ranks share one card to rehearse the N > 1 control flow
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes one and starts the ranks (nothing here has touched the GPU yet)
+        import torch
+
+        have = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+        if backend == "nccl" and have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d asked for, %d GPU(s) visible (RT_BENCH_BACKEND=gloo rehearses the "
+                             "N > 1 control flow with the ranks sharing a card)" % (args.gpus, have))
+        raise SystemExit(spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -146,10 +236,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # the line's n_gpus must be what was asked for: a launcher that started another number of ranks is an error
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the core has no CPU path")
-    # one process per GPU; RT_BENCH_BACKEND=gloo lets several ranks share one card to rehearse the N > 1 control flow
-    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
     if world > 1:
@@ -268,8 +359,13 @@ def main():
     t_start = time.perf_counter()
     for i in range(my_steps):
         step(args.warmup + i)
+    reduce_ms = None
     if world > 1 and args.workload != "closest_hit":
+        torch.cuda.synchronize()
+        t_red = time.perf_counter()
         reduce_sum(accum)
+        torch.cuda.synchronize()
+        reduce_ms = (time.perf_counter() - t_red) * 1e3
     barrier()
     elapsed = time.perf_counter() - t_start
     st = scene.stats()
@@ -277,11 +373,20 @@ def main():
 
     t_all = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     r_all = torch.tensor([float(st.rays)], dtype=torch.float64, device="cuda")
+    seen = torch.ones(1, dtype=torch.float64, device="cuda")  # every rank that takes part adds one
+    red = torch.tensor([reduce_ms or 0.0], dtype=torch.float64, device="cuda")
     if world > 1:
+        if backend != "nccl":  # (gloo reduces host tensors)
+            t_all, r_all, seen, red = t_all.cpu(), r_all.cpu(), seen.cpu(), red.cpu()
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(r_all, op=dist.ReduceOp.SUM)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        dist.all_reduce(red, op=dist.ReduceOp.MAX)
     elapsed_max = float(t_all.item())
     rays_total = float(r_all.item())
+    ranks_seen = int(round(float(seen.item())))
+    if ranks_seen != args.gpus:
+        raise SystemExit("bench.py: %d rank(s) took part, --gpus %d was asked for" % (ranks_seen, args.gpus))
 
     if rank == 0:
         value = rays_total / elapsed_max / 1e6
@@ -321,23 +426,42 @@ def main():
             clock = e.get("clock_GHz_under_profile") or MAX_CLOCK_GHZ
             prof_launch_s = e["mean_launch_ms"] / 1e3
             cu_cycles = prof_launch_s * clock * 1e9 * N_CU  # CU-cycles of one launch
-            # vector ALU: G lane-op/s at one wave64 instruction per 4 SIMD cycles on every SIMD ("VALU busy = 1, all lanes active")
-            valu_peak = N_SIMD * 64 / 4.0 * clock
-            # (the busy figure is rocprof's VALUBusy; it comes out a little above 1 when the unit never idles, because
-            # some instructions issue in fewer than four cycles: capped)
-            valu_frac = min(1.0, e["valu_busy_fraction"]) * e["valu_lane_utilisation"]
+            simd_cycles = cu_cycles * 4
+            # Vector ALU.  The ceiling is MEASURED (tools/ubench/valu_rate.hip, cycles from s_memtime inside the kernel):
+            # cycles per vector instruction and SIMD of the node step's own code on register-resident nodes, all 64
+            # lanes active, no memory access, at the waves per SIMD the kernel runs with.  peak = every SIMD issuing at
+            # that rate with every lane useful; achieved = the kernel's vector instructions x active lanes per
+            # instruction; frac = issue_frac x lane utilisation.
+            ceil = valu_ceiling(int(e.get("waves_per_simd", 7)))
+            valu_insts, salu_insts = e["SQ_INSTS_VALU_per_launch"], e["SQ_INSTS_SALU_per_launch"]
+            cycles_per_valu = simd_cycles / valu_insts
+            issue_frac = ceil["cycles_per_vector_instruction"] / cycles_per_valu
+            lane_util = e["valu_lane_utilisation"]
+            valu_peak = N_SIMD * 64 * clock / ceil["cycles_per_vector_instruction"]  # G lane-op/s
+            valu_achieved = valu_insts * 64 * lane_util / prof_launch_s / 1e9
             factor, factor_note = fetch_factor()
             hbm_bytes = e["hbm_bytes_per_launch_raw"] * factor
-            valu = {"achieved_G_lane_op_per_s": round(valu_frac * valu_peak, 1), "peak_G_lane_op_per_s": round(valu_peak, 1),
-                    "frac": round(valu_frac, 4), "valu_busy": round(e["valu_busy_fraction"], 4),
-                    "valu_lane_utilisation": round(e["valu_lane_utilisation"], 4),
-                    "salu_per_valu_inst": round(e["SQ_INSTS_SALU_per_launch"] / e["SQ_INSTS_VALU_per_launch"], 3)}
+            valu = {"achieved_G_lane_op_per_s": round(valu_achieved, 1), "peak_G_lane_op_per_s": round(valu_peak, 1),
+                    "frac": round(issue_frac * lane_util, 4), "issue_frac": round(issue_frac, 4),
+                    "valu_lane_utilisation": round(lane_util, 4),
+                    "cycles_per_vector_instruction_and_simd": round(cycles_per_valu, 3),
+                    "ceiling_cycles_per_vector_instruction_and_simd": ceil["cycles_per_vector_instruction"],
+                    "ceiling_source": ceil["source"],
+                    "scalar_per_vector_inst": round(salu_insts / valu_insts, 3),
+                    # scalar instructions take issue time too: the ceiling of a 2 : 1 vector : scalar stream (about the
+                    # kernel's ratio) and the kernel's fraction of THAT
+                    "ceiling_2_to_1_vector_scalar_stream": ceil.get("cycles_per_vector_instruction_2_to_1_scalar"),
+                    "issue_frac_of_2_to_1_stream": round(ceil["cycles_per_vector_instruction_2_to_1_scalar"] / cycles_per_valu, 4)
+                    if ceil.get("cycles_per_vector_instruction_2_to_1_scalar") else None,
+                    "rocprof_valu_busy": round(e["valu_busy_fraction"], 4),
+                    "wait_any_frac_of_wave_cycles": round(e["SQ_WAIT_ANY_per_launch"] / e["SQ_WAVE_CYCLES_per_launch"], 4)
+                    if e.get("SQ_WAIT_ANY_per_launch") and e.get("SQ_WAVE_CYCLES_per_launch") else None}
             hbm = {"achieved_GBps": round(hbm_bytes / prof_launch_s / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
                    "frac": round(hbm_bytes / prof_launch_s / 1e9 / HBM_PEAK_GBS, 4),
                    "fetch_size_raw_bytes": int(e["hbm_bytes_per_launch_raw"]), "factor": factor, "factor_note": factor_note,
                    "l2_hit_rate": round(e.get("l2_hit_rate", 0.0), 4)}
             roof.update({"traffic": int(hbm_bytes), "valu": valu, "hbm": hbm,
-                         "profile": {"file": prof["_file"], "source_hash": prof["source_hash"], "git_head": prof.get("git_head", ""),
+                         "profile": {"file": prof["_file"], "source_hash": prof["source_hash"],
                                      "mean_launch_ms_under_profile": round(e["mean_launch_ms"], 3),
                                      "note": "counters from separate rocprofv3 --pmc runs of this configuration (one run per counter group), "
                                              "not from this run"}})
@@ -357,7 +481,10 @@ def main():
                               "tools/ubench/node_fetch.hip reaches with this load shape; TA / TD busy = the address and "
                               "data-return units' busy cycles / cycles (TD busy includes its waiting for the L1)"}
                 roof["l1"] = l1
-            if l1 is not None and l1["frac"] > min(1.0, e["valu_busy_fraction"]):
+            # the unit that is busier names the bound: the instruction issue of the SIMDs (against the measured ceiling of
+            # a stream with the kernel's share of scalar instructions) or the CU's vector memory path
+            issue_busy = valu["issue_frac_of_2_to_1_stream"] or issue_frac
+            if l1 is not None and l1["frac"] > issue_busy:
                 roof.update({"bound": "l1", "unit": "G line accesses/s", "achieved": l1["achieved_G_line_accesses_per_s"],
                              "peak": l1["peak_G_line_accesses_per_s"], "frac": l1["frac"]})
             else:
@@ -379,6 +506,7 @@ def main():
             "value": round(value, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": steps_reported,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / max(1, steps_reported) * 1e3, 3),
@@ -395,8 +523,12 @@ def main():
                 "primitives": int(info.n_primitives), "wide_nodes": int(info.n_wide_nodes),
                 "scene_MB": round(info.device_bytes / 1e6, 1),
                 "parallelism": ("%d passes in all, " % args.total_passes if strong else "") +
-                               "passes round-robin over %d GPU(s), scene replicated, one RCCL sum (%s)" % (
-                                   world, "library" if use_native else "torch.distributed"),
+                               "passes round-robin over %d GPU(s), scene replicated, %s" % (
+                                   world, "no collective (one rank)" if world == 1 else
+                                   "one RCCL sum (the library's ncclReduce)" if use_native else
+                                   "one RCCL sum (torch.distributed.reduce)" if backend == "nccl" else
+                                   "one sum through the host (%s back end: a rehearsal, not RCCL)" % backend),
+                "reduce_ms": round(float(red.item()), 3) if world > 1 and args.workload != "closest_hit" else None,
                 "s_per_4k_frame": round(elapsed_max / max(1, my_steps), 4) if (W, H) == (3840, 2160) else None,
                 "rays_per_step_per_gpu": int(st.rays / max(1, my_steps)),
                 "scene_gen_s": round(t_gen, 2), "scene_build_s": round(t_build, 2),

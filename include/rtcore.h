@@ -296,6 +296,8 @@ int rt_closest_hit_batch_counted_device(RtScene *scene, const float *d_org_dir, 
  * same results as rt_closest_hit_batch_device; the work memory (packed rays, hit records, the launch's work
  * counter, the overflow area of the traversal stacks) is a 64 MiB array that each GPU the library runs on
  * holds from load time until the process ends, so the call issues no hipMalloc / hipFree and creates no events.
+ * Cost: those 64 MiB of HBM are taken on EVERY GPU of every process that loads the library, whether or not this
+ * entry point is ever called (the array is part of the library's device code).
  * Limits: n <= RT_NOALLOC_MAX_RAYS per call (RT_ERR_INVALID_ARGUMENT beyond it); the launch uses fewer blocks
  * when the scene's tree is deep, so that the stacks' overflow area fits.  RtStats is not updated.  Every call
  * on a GPU uses that GPU's one array: calls that overlap on one GPU (two streams, two threads) race; calls on

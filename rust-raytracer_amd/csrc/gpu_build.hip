@@ -1025,7 +1025,7 @@ int build_device_scene(const RtSceneDesc *d, DeviceBuild &out, std::string &err)
     size_t sort_tmp_bytes = 0;
     GB_HIP(rocprim::radix_sort_pairs(nullptr, sort_tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr,
                                      (uint32_t *)nullptr, n, 0, 63, (hipStream_t)0));
-    const char *tree_env = std::getenv("RTCORE_DEVICE_TREE");
+    const char *tree_env = experiment_env("RTCORE_DEVICE_TREE");
     const bool morton_tree = tree_env && std::strcmp(tree_env, "morton") == 0;  // the Morton-order tree instead of the median splits
     {
         size_t scan_bytes = 0;
@@ -1174,7 +1174,7 @@ int build_device_scene(const RtSceneDesc *d, DeviceBuild &out, std::string &err)
     GB_HIP(hipGetLastError());
 
     uint32_t n_wide = 0, depth = 0;
-    const char *collapse = std::getenv("RTCORE_COLLAPSE");
+    const char *collapse = experiment_env("RTCORE_COLLAPSE");
     const int greedy = (collapse && std::strcmp(collapse, "greedy") == 0) ? 1 : 0;
     if (n <= 2) {
         hipLaunchKernelGGL(tiny_tree_kernel, dim3(1), dim3(64), 0, stream, (int)n, leaf_lo, leaf_hi, node_lo, node_hi, wide);

@@ -47,6 +47,7 @@ struct Rccl {
     int (*CommInitRank)(NcclComm *, int, NcclUniqueId, int) = nullptr;
     int (*CommInitAll)(NcclComm *, int, const int *) = nullptr;
     int (*CommDestroy)(NcclComm) = nullptr;
+    int (*CommAbort)(NcclComm) = nullptr;  // optional
     int (*Reduce)(const void *, void *, size_t, int, int, int, NcclComm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
@@ -65,13 +66,21 @@ const Rccl &rccl() {
                 return;
             }
         }
-        // the soname first: a copy that is already in the process (PyTorch's) is found under it
+        // the soname first: a copy that is already in the process (PyTorch's) is found under it;
+        // RTCORE_RCCL_LIB names the one file to try instead (a test points it at a file that does not exist)
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const char *only = std::getenv("RTCORE_RCCL_LIB");
         void *h = nullptr;
-        for (const char *n : names)
+        std::string last_error;
+        for (const char *n : names) {
+            if (only && *only) n = only;
             if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+            const char *e = dlerror();  // (reading the message clears it: one call per failure)
+            last_error = e ? e : "";
+            if (only && *only) break;
+        }
         if (!h) {
-            g_rccl.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+            g_rccl.why = "librccl not found: " + last_error;
             return;
         }
         Rccl r;
@@ -79,6 +88,7 @@ const Rccl &rccl() {
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
         r.CommInitAll = (decltype(r.CommInitAll))dlsym(h, "ncclCommInitAll");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
         r.Reduce = (decltype(r.Reduce))dlsym(h, "ncclReduce");
         r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
@@ -112,6 +122,7 @@ struct RtMulti {
     size_t accum_floats = 0;
     float *stage = nullptr;  // on devices[0]: landing buffer of the peer-copy sum
     size_t stage_floats = 0;
+    std::vector<float> host;  // landing buffer of the one download per rt_render_passes_multi call (kept between calls)
     std::vector<NcclComm> comms;  // ncclCommInitAll over the devices, made on first use
     bool distinct = true;         // no device named twice
     int last_reduce = 0;          // 1 RCCL, 2 peer copies
@@ -178,18 +189,41 @@ int reduce_rccl(RtMulti *m, float *const *bufs, size_t n) {
             return fail(RT_ERR_DEVICE, nccl_msg("ncclCommInitAll", rc));
         }
     }
+    // A failure inside the group leaves the communicators in an unknown state: the group is closed, the communicators
+    // are given up (aborted where the library can, so nothing waits for the replicas that were never enqueued) and the
+    // next call makes new ones or takes the peer-copy sum.
+    auto give_up = [&](const char *what, int code) {
+        for (NcclComm c : m->comms)
+            if (c) (void)(r.CommAbort ? r.CommAbort(c) : r.CommDestroy(c));
+        m->comms.clear();
+        return fail(RT_ERR_DEVICE, nccl_msg(what, code));
+    };
+    for (int g = 0; g < nd; g++)
+        if (!bufs[g]) return fail(RT_ERR_INVALID_ARGUMENT, "null accumulator");
     int rc = r.GroupStart();
-    if (rc != kNcclSuccess) return fail(RT_ERR_DEVICE, nccl_msg("ncclGroupStart", rc));
-    for (int g = 0; g < nd; g++) {
-        RT_HIP(hipSetDevice(m->devices[g]));
-        rc = r.Reduce(bufs[g], bufs[g], n, kNcclFloat32, kNcclSum, 0, m->comms[(size_t)g], m->streams[(size_t)g]);
-        if (rc != kNcclSuccess) {
-            (void)r.GroupEnd();
-            return fail(RT_ERR_DEVICE, nccl_msg("ncclReduce", rc));
+    if (rc != kNcclSuccess) return give_up("ncclGroupStart", rc);
+    int bad = kNcclSuccess;
+    for (int g = 0; g < nd && bad == kNcclSuccess; g++) {
+        if (hipSetDevice(m->devices[g]) != hipSuccess) {
+            bad = -1;
+            break;
         }
+        bad = r.Reduce(bufs[g], bufs[g], n, kNcclFloat32, kNcclSum, 0, m->comms[(size_t)g], m->streams[(size_t)g]);
+    }
+    if (bad != kNcclSuccess) {
+        // every replica's call must be enqueued before the group can complete: abort the communicators first, then
+        // close the group (an aborted communicator's pending work returns instead of waiting)
+        for (NcclComm c : m->comms)
+            if (c && r.CommAbort) (void)r.CommAbort(c);
+        (void)r.GroupEnd();
+        if (!r.CommAbort)
+            for (NcclComm c : m->comms)
+                if (c) (void)r.CommDestroy(c);
+        m->comms.clear();
+        return fail(RT_ERR_DEVICE, bad == -1 ? std::string("hipSetDevice failed") : nccl_msg("ncclReduce", bad));
     }
     rc = r.GroupEnd();
-    if (rc != kNcclSuccess) return fail(RT_ERR_DEVICE, nccl_msg("ncclGroupEnd", rc));
+    if (rc != kNcclSuccess) return give_up("ncclGroupEnd", rc);
     for (int g = 0; g < nd; g++) {
         RT_HIP(hipSetDevice(m->devices[g]));
         RT_HIP(hipStreamSynchronize(m->streams[(size_t)g]));
@@ -235,9 +269,11 @@ int rt_multi_gpu_destroy(RtMulti *m) {
     if (!m) return RT_OK;
     int before = 0;
     (void)hipGetDevice(&before);
-    const Rccl &r = rccl();
-    for (NcclComm c : m->comms)
-        if (c && r.ok()) (void)r.CommDestroy(c);
+    if (!m->comms.empty()) {  // (communicators exist only if RCCL was loaded: no look-up otherwise)
+        const Rccl &r = rccl();
+        for (NcclComm c : m->comms)
+            if (c && r.ok()) (void)r.CommDestroy(c);
+    }
     for (size_t g = 0; g < m->devices.size(); g++) {
         (void)hipSetDevice(m->devices[g]);
         if (m->streams[g]) {
@@ -262,7 +298,9 @@ int rt_multi_gpu_last_reduce(const RtMulti *m) { return m ? m->last_reduce : 0; 
 
 int rt_reduce(RtMulti *m, float *const *d_bufs, size_t n_floats, int how) {
     if (!m || !d_bufs || how < 0 || how > 2) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
-    if (n_floats == 0 || m->devices.size() == 1) return RT_OK;
+    // one replica: nothing to add; an explicit request for RCCL still goes through it (a one-rank communicator's
+    // in-place reduce), so that the path can be exercised on a single GPU
+    if (n_floats == 0 || (m->devices.size() == 1 && how != 1)) return RT_OK;
     int before = 0;
     RT_HIP(hipGetDevice(&before));
     int rc;
@@ -316,9 +354,10 @@ int rt_render_passes_multi(RtMulti *m, const RtRenderParams *params, uint32_t fi
     rc = rt_reduce(m, m->accum.data(), n, 0);
     if (rc == RT_OK) {
         // the one PCIe transfer of the render: the summed frame comes down and is added to the caller's buffer
-        std::vector<float> host(n);
+        if (m->host.size() < n) m->host.resize(n);
+        const float *host = m->host.data();
         if (hipSetDevice(m->devices[0]) != hipSuccess ||
-            hipMemcpy(host.data(), m->accum[0], n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+            hipMemcpy(m->host.data(), m->accum[0], n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
             rc = fail(RT_ERR_DEVICE, "download of the summed frame failed");
         else
             for (size_t i = 0; i < n; i++) accum_rgb[i] = accum_rgb[i] + host[i];
@@ -370,9 +409,10 @@ int rt_comm_init_rank(const unsigned char id[128], int rank, int world, RtComm *
     if (!r.ok()) return fail(RT_ERR_DEVICE, "RCCL is not usable: " + r.why);
     NcclUniqueId u;
     std::memcpy(u.internal, id, 128);
+    int device = 0;
+    RT_HIP(hipGetDevice(&device));
     RtComm *c = new RtComm();
-    c->rank = rank, c->world = world;
-    RT_HIP(hipGetDevice(&c->device));
+    c->rank = rank, c->world = world, c->device = device;
     int rc = r.CommInitRank(&c->comm, world, u, rank);
     if (rc != kNcclSuccess) {
         delete c;
@@ -385,6 +425,7 @@ int rt_comm_init_rank(const unsigned char id[128], int rank, int world, RtComm *
 int rt_comm_reduce(RtComm *c, float *d_buf, size_t n_floats, int root, void *stream) {
     if (!c || !d_buf || root < 0 || root >= c->world) return fail(RT_ERR_INVALID_ARGUMENT, "bad argument");
     const Rccl &r = rccl();
+    if (!r.ok() || !c->comm) return fail(RT_ERR_DEVICE, "RCCL is not usable: " + r.why);
     int rc = r.Reduce(d_buf, d_buf, n_floats, kNcclFloat32, kNcclSum, root, c->comm, (hipStream_t)stream);
     if (rc != kNcclSuccess) return fail(RT_ERR_DEVICE, nccl_msg("ncclReduce", rc));
     return RT_OK;

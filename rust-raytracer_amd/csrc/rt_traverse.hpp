@@ -27,21 +27,30 @@
 
 #include "rt_device.hpp"
 
+#ifndef RT_SORT_EXCHANGES
+#define RT_SORT_EXCHANGES 5
+#endif
+
 namespace rtd {
 
 struct Best {
     float t;
-    int32_t index;  // visit rank = index into the primitive array, -1 = none
-    bool ties;      // does the best primitive's own bound check accept t == t_max
+    // 2 * visit rank (= index into the primitive array) + 1 if the primitive's own bound check accepts t == t_max;
+    // kBestNone = no hit yet.  One register for both: two candidates never share a rank, so comparing keys
+    // compares ranks.
+    int32_t key;
+    RT_DEV int32_t index() const { return key >> 1; }  // -1 = none
 };
+constexpr int32_t kBestNone = -2;
 
 // `valid` = the primitive's own test passed; written without branches (the lanes of a wave test
 // different primitives, so an early exit never lets the wave skip anything)
 RT_DEV void consider(Best &b, bool valid, float t, bool ties, int32_t index) {
-    bool closer = valid && ((t < b.t) || (t == b.t && ((index > b.index) ? ties : !b.ties)));
+    const int32_t key = index * 2 + (ties ? 1 : 0);
+    const bool tie_goes = (key > b.key) ? ties : ((b.key & 1) == 0);
+    const bool closer = valid & ((t < b.t) | ((t == b.t) & tie_goes));
     b.t = closer ? t : b.t;
-    b.index = closer ? index : b.index;
-    b.ties = closer ? ties : b.ties;
+    b.key = closer ? key : b.key;
 }
 
 // ABox::hit without the normal (src/tracer/cube.rs:42-56): candidate t and whether it is the entry face
@@ -93,30 +102,34 @@ RT_DEV Ray cube_local_ray(F3 center, Rotor rot, const Ray &ray) {
     return l;
 }
 
-// Tests the primitive whose record is (r0, r1, r2) and offers its candidate to `best`.  t_max is the ray's own bound.
-RT_DEV void test_record(float4 r0, float4 r1, float4 r2, int32_t index, const Ray &ray, F3 inv, float t_min,
-                        float t_max, Best &best) {
+// Triangle::hit (src/tracer/triangle.rs:37-66) on the record (r0, r1, r2); e1, e2 are stored, they are the same floats.
+// The reference's early returns are one predicate over the same expressions; `valid` = there is a triangle to test.
+RT_DEV void test_triangle(float4 r0, float4 r1, float4 r2, int32_t index, const Ray &ray, float t_min, float t_max,
+                          bool valid, Best &best) {
+    const bool two_sided = (__float_as_uint(r2.z) & RT_PRIM_FLAG) != 0;
+    F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
+    F3 h = cross(ray.d, e2);
+    float a = dot(e1, h);
+    bool ok = valid & !((!two_sided & ((__float_as_uint(a) >> 31) != 0u)) | (fabsf(a) < 1e-6f));
+    float f = 1.0f / a;
+    F3 s = ray.o - v0;
+    float u = f * dot(s, h);
+    ok = ok & ((u >= 0.0f) & (u <= 1.0f));
+    F3 q = cross(s, e1);
+    float v = f * dot(ray.d, q);
+    ok = ok & !((v < 0.0f) | (u + v > 1.0f));
+    float t = f * dot(e2, q);
+    ok = ok & !((t < t_min) | (t > t_max));
+    consider(best, ok, t, true, index);
+}
+
+// Tests the primitive whose record is (r0, r1, r2), of a type other than triangle, and offers its candidate to `best`.
+// t_max is the ray's own bound.
+RT_DEV void test_record_other(float4 r0, float4 r1, float4 r2, int32_t index, const Ray &ray, F3 inv, float t_min,
+                              float t_max, Best &best) {
     uint32_t meta = __float_as_uint(r2.z);
     uint32_t type = meta & RT_PRIM_TYPE_MASK;
-    bool flag = (meta & RT_PRIM_FLAG) != 0;
-    if (type == RT_PRIM_TRIANGLE) {
-        // Triangle::hit (src/tracer/triangle.rs:37-66); e1, e2 are stored, they are the same floats
-        F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
-        // the reference's early returns, as one predicate over the same expressions
-        F3 h = cross(ray.d, e2);
-        float a = dot(e1, h);
-        bool ok = !((!flag && (__float_as_uint(a) >> 31)) || fabsf(a) < 1e-6f);
-        float f = 1.0f / a;
-        F3 s = ray.o - v0;
-        float u = f * dot(s, h);
-        ok = ok && (u >= 0.0f && u <= 1.0f);
-        F3 q = cross(s, e1);
-        float v = f * dot(ray.d, q);
-        ok = ok && !(v < 0.0f || u + v > 1.0f);
-        float t = f * dot(e2, q);
-        ok = ok && !(t < t_min || t > t_max);
-        consider(best, ok, t, true, index);
-    } else if (type == RT_PRIM_SPHERE) {
+    if (type == RT_PRIM_SPHERE) {
         // Sphere::hit (src/tracer/sphere.rs:28-58)
         F3 c = f3(r0.x, r0.y, r0.z);
         float radius = r0.w;
@@ -150,10 +163,19 @@ RT_DEV void test_record(float4 r0, float4 r1, float4 r2, int32_t index, const Ra
     }
 }
 
-// HitRecord fields of the winning primitive: normal, material, primitive id.
-RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, const Best &best, F3 *normal, uint32_t *material,
+// Tests the primitive whose record is (r0, r1, r2), of any type.
+RT_DEV void test_record(float4 r0, float4 r1, float4 r2, int32_t index, const Ray &ray, F3 inv, float t_min,
+                        float t_max, Best &best) {
+    if ((__float_as_uint(r2.z) & RT_PRIM_TYPE_MASK) == RT_PRIM_TRIANGLE)
+        test_triangle(r0, r1, r2, index, ray, t_min, t_max, true, best);
+    else
+        test_record_other(r0, r1, r2, index, ray, inv, t_min, t_max, best);
+}
+
+// HitRecord fields of the winning primitive (visit rank `index`, distance `t`): normal, material, primitive id.
+RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, float t, int32_t index, F3 *normal, uint32_t *material,
                        int32_t *prim_id) {
-    const float4 *r = (const float4 *)sc.shade_records + (size_t)best.index * (2 * RT_PRIM_FLOAT4S);
+    const float4 *r = (const float4 *)sc.shade_records + (size_t)index * (2 * RT_PRIM_FLOAT4S);
     float4 r0 = r[0], r1 = r[1], r2 = r[2];
     uint32_t meta = __float_as_uint(r2.z);
     uint32_t type = meta & RT_PRIM_TYPE_MASK;
@@ -176,16 +198,16 @@ RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, const Best &best, 
         F3 n0 = f3(a.x, a.y, a.z), n1 = f3(b.x, b.y, b.z), n2 = f3(c.x, c.y, c.z);
         *normal = normalized((1.0f - (u + v)) * n0 + u * n1 + v * n2);
     } else if (type == RT_PRIM_SPHERE) {
-        F3 p = ray_at(ray, best.t);
+        F3 p = ray_at(ray, t);
         *normal = normalized(p - f3(r0.x, r0.y, r0.z));
     } else if (type == RT_PRIM_ABOX) {
-        *normal = abox_normal(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), ray_at(ray, best.t), flag);
+        *normal = abox_normal(f3(r0.x, r0.y, r0.z), f3(r0.w, r1.x, r1.y), ray_at(ray, t), flag);
     } else {
         // Cube::hit (src/tracer/cube.rs:110-117): the face is matched in the box's frame
         F3 center = f3(r0.x, r0.y, r0.z), half = f3(r0.w, r1.x, r1.y);
         Rotor rot{r1.z, r1.w, r2.x, r2.y};
         Ray local = cube_local_ray(center, rot, ray);
-        F3 nl = abox_normal(center - half, center + half, ray_at(local, best.t), flag);
+        F3 nl = abox_normal(center - half, center + half, ray_at(local, t), flag);
         *normal = rotate(rot, nl);
     }
 }
@@ -231,8 +253,7 @@ template <bool COUNT>
 RT_DEV bool traversal_begin(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, float t_max,
                             uint32_t *visits) {
     tr.best.t = t_max;
-    tr.best.index = -1;
-    tr.best.ties = false;
+    tr.best.key = kBestNone;
     st.sp = 0;
     tr.entry = 0;  // node 0
     const Ray &ray = tr.ray;
@@ -255,39 +276,38 @@ RT_DEV bool traversal_begin(const RtSceneView &sc, Traversal &tr, Stack &st, flo
     return tn <= tf;
 }
 
-// One turn of taking the next entry from the stack; an entry whose box starts beyond the best hit
-// is dropped (and the lane still wants an entry).  Sets `finished` when the stack has run empty.
-// Returns true while the lane still wants an entry.
-RT_DEV bool traversal_pop_turn(Traversal &tr, Stack &st, bool &finished) {
-    if (st.sp <= 0) {
-        finished = true;
-        return false;
-    }
-    if (st.sp > RT_LDS_STACK) {  // the top entry is in the overflow area
+// What a lane of the closest-hit kernel is doing.  The two kinds of step come first, so that the leaf bit of the
+// child word a lane goes on with IS its next state; a lane with state >= kParked has no ray at work.
+constexpr uint32_t kAtNode = 0u, kAtLeaf = 1u, kPopping = 2u, kParked = 3u, kEmpty = 4u;
+static_assert((RT_CHILD_LEAF >> 31) == kAtLeaf, "a child word's top bit is the lane's next state");
+
+// One turn of taking the next entry from the stack: the two top entries are read in one LDS round trip; an entry
+// whose box starts beyond the best hit is dropped.  Returns the lane's next state: at a node / at a leaf (tr.entry
+// is the entry taken), still popping (both entries were dead and more remain), or parked (the stack has run empty:
+// the traversal is finished).  Straight-line code but for the rare lane whose top entry is in the overflow area.
+RT_DEV uint32_t traversal_pop_turn(Traversal &tr, Stack &st) {
+    if (st.sp > RT_LDS_STACK) {
         uint32_t w;
         float t;
         st.pop(&w, &t);
         if (t <= tr.best.t) {
             tr.entry = w;
-            return false;
+            return w >> 31;
         }
-        return true;
+        return kPopping;
     }
-    // the two top entries in one LDS round trip
-    const int below = st.sp >= 2 ? st.sp - 2 : 0;
-    const uint2 e1 = st.lds[(st.sp - 1) * st.lds_stride], e2 = st.lds[below * st.lds_stride];
-    if (__uint_as_float(e1.y) <= tr.best.t) {
-        tr.entry = e1.x;
-        st.sp -= 1;
-        return false;
-    }
-    if (st.sp >= 2 && __uint_as_float(e2.y) <= tr.best.t) {
-        tr.entry = e2.x;
-        st.sp -= 2;
-        return false;
-    }
-    st.sp = below;
-    return true;
+    const int top = st.sp >= 1 ? st.sp - 1 : 0, below = st.sp >= 2 ? st.sp - 2 : 0;
+    uint2 e1 = st.lds[top * st.lds_stride], e2 = st.lds[below * st.lds_stride];
+    // (both entries are read whole and unconditionally -- row 0 exists for every lane -- so that the turn is two LDS
+    // reads and a handful of selects, no branch)
+    asm volatile("" : "+v"(e1.x), "+v"(e1.y), "+v"(e2.x), "+v"(e2.y));
+    const bool ok1 = (st.sp >= 1) & (__uint_as_float(e1.y) <= tr.best.t);
+    const bool ok2 = (st.sp >= 2) & (__uint_as_float(e2.y) <= tr.best.t);
+    const uint32_t w = ok1 ? e1.x : e2.x;
+    st.sp = ok1 ? top : below;
+    tr.entry = w;
+    const uint32_t dry = st.sp == 0 ? kParked : kPopping;
+    return (ok1 | ok2) ? (w >> 31) : dry;
 }
 
 // tr.entry is a leaf: tests its primitives.  The lane then wants the next stack entry.
@@ -432,9 +452,17 @@ RT_DEV void node_fetch_own(const RtSceneView &sc, uint32_t entry, NodeWords &w) 
 }
 
 // After the slab tests of a node step: pushes the far hit children and continues with the nearest.  `key` / `cw` are the
-// sorted pairs (the hit children are the pairs [4 - nh, 4), nearest first).  Returns true when no child was hit: the lane
-// then wants the next stack entry.
-RT_DEV bool traversal_descend(const int nh, const float key[4], const uint32_t cw[4], Traversal &tr, Stack &st) {
+// sorted pairs (the hit children are the pairs [4 - nh, 4), nearest first).  Returns the lane's next state: at the
+// nearest hit child (a node or a leaf), or popping when no child was hit.
+RT_DEV uint32_t traversal_descend(const int nh, const float key[4], const uint32_t cw[4], Traversal &tr, Stack &st) {
+    // the nearest hit child is pair 4 - nh: three selects (kept apart from the stores' branch below, so that they stay
+    // selects)
+    uint32_t next = cw[3];
+    next = nh >= 2 ? cw[2] : next;
+    next = nh >= 3 ? cw[1] : next;
+    next = nh >= 4 ? cw[0] : next;
+    uint32_t after = nh == 0 ? kPopping : (next >> 31);
+    asm volatile("" : "+v"(next), "+v"(after));
     // The farthest goes to the stack first, the nearest continues.  Pairs 3, 2, 1 are written to the three entries above
     // the top whether they are hit children or not: what is not one lies above the new top, where nothing reads it.
     if (st.sp + 3 <= RT_LDS_STACK) {
@@ -448,14 +476,14 @@ RT_DEV bool traversal_descend(const int nh, const float key[4], const uint32_t c
         if (nh > 3) st.store(st.sp + 2, cw[1], key[1]);
     }
     st.sp += nh > 1 ? nh - 1 : 0;
-    tr.entry = nh == 1 ? cw[3] : (nh == 2 ? cw[2] : (nh == 3 ? cw[1] : cw[0]));
-    return nh == 0;
+    tr.entry = next;
+    return after;
 }
 
 // tr.entry is a node whose words are `w`: tests its four child boxes, pushes the far hits and continues with the
-// nearest.  Returns true when no child was hit: the lane then wants the next stack entry.
+// nearest.  Returns the lane's next state.
 template <bool COUNT>
-RT_DEV bool traversal_node_process(const NodeWords &w, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
+RT_DEV uint32_t traversal_node_process(const NodeWords &w, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
     if (COUNT) (*visits)++;
     float key[4];
     uint32_t cw[4];
@@ -464,7 +492,7 @@ RT_DEV bool traversal_node_process(const NodeWords &w, Traversal &tr, Stack &st,
 }
 
 template <bool COUNT>
-RT_DEV bool traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
+RT_DEV uint32_t traversal_node_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
     NodeWords w;
     node_fetch_own(sc, tr.entry, w);
     return traversal_node_process<COUNT>(w, tr, st, t_min, visits);
@@ -561,8 +589,9 @@ RT_DEV int qnode_children_sorted(const QNodeWords &w, const F3 o, const F3 inv, 
     nh += grid_child<1>(x, y, z, cw[1], t_min, t_best, &key[1]) ? 1 : 0;
     nh += grid_child<2>(x, y, z, cw[2], t_min, t_best, &key[2]) ? 1 : 0;
     nh += grid_child<3>(x, y, z, cw[3], t_min, t_best, &key[3]) ? 1 : 0;
+    // any bound that is infinite or not a number makes the sum so (the bounds are sums of magnitudes: no cancellation)
     const float kHuge = 3.0e38f;
-    if (!(x.bound < kHuge && y.bound < kHuge && z.bound < kHuge)) {
+    if (!((x.bound + y.bound) + z.bound < kHuge)) {
         nh = plane_child<0>(w, cw[0], o, inv, t_min, t_best, &key[0]) ? 1 : 0;
         nh += plane_child<1>(w, cw[1], o, inv, t_min, t_best, &key[1]) ? 1 : 0;
         nh += plane_child<2>(w, cw[2], o, inv, t_min, t_best, &key[2]) ? 1 : 0;
@@ -577,13 +606,16 @@ RT_DEV int qnode_children_sorted(const QNodeWords &w, const F3 o, const F3 inv, 
         const uint32_t wj = sw ? cw[i] : cw[j];         \
         key[i] = ki, key[j] = kj, cw[i] = wi, cw[j] = wj; \
     }
-    RT_CSEL(0, 1) RT_CSEL(2, 3) RT_CSEL(0, 2) RT_CSEL(1, 3) RT_CSEL(1, 2)
+    RT_CSEL(0, 1) RT_CSEL(2, 3) RT_CSEL(0, 2) RT_CSEL(1, 3)
+#if RT_SORT_EXCHANGES >= 5
+    RT_CSEL(1, 2)
+#endif
 #undef RT_CSEL
     return nh;
 }
 
 template <bool COUNT>
-RT_DEV bool traversal_qnode_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
+RT_DEV uint32_t traversal_qnode_step(const RtSceneView &sc, Traversal &tr, Stack &st, float t_min, uint32_t *visits) {
     QNodeWords w;
     qnode_fetch_own(sc, tr.entry, w);
     if (COUNT) (*visits)++;
@@ -612,20 +644,32 @@ RT_DEV void traversal_guarded_leaf_step(const RtSceneView &sc, Traversal &tr, fl
     const F3 t1 = (f3(g0.w, g1.x, g1.y) - tr.ray.o) * tr.inv;
     const float tn = fmaxf(max3(f3(fminf(t0.x, t1.x), fminf(t0.y, t1.y), fminf(t0.z, t1.z))), t_min);
     const float tf = fminf(min3(f3(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y), fmaxf(t0.z, t1.z))), tr.best.t);
-    const bool open = tn <= tf;
-    const int32_t first = (int32_t)__float_as_uint(g1.z);
+    // (decided here, before the primitives' tests, and kept as one register: the guard's words are then free)
+    uint32_t open_bit = tn <= tf ? 1u : 0u;
+    int32_t first = (int32_t)__float_as_uint(g1.z);
+    asm volatile("" : "+v"(open_bit), "+v"(first));
+    const bool open = open_bit != 0u;
     if (COUNT) (*tests) += open ? (uint32_t)count : 0u;
     Best best = tr.best;
-    test_record(a0, a1, a2, first, tr.ray, tr.inv, t_min, t_max, best);
-    if (two) test_record(b0, b1, b2, first + 1, tr.ray, tr.inv, t_min, t_max, best);
-    for (int32_t k = 2; k < count; k += 2) {  // (no builder makes such leaves today)
-        const float4 *q = b + (size_t)(k >> 1) * RT_LEAF_BLOCK_FLOAT4S;
-        test_record(q[2], q[3], q[4], first + k, tr.ray, tr.inv, t_min, t_max, best);
-        if (k + 1 < count) test_record(q[5], q[6], q[7], first + k + 1, tr.ray, tr.inv, t_min, t_max, best);
+    // Meshes are what large scenes are made of, so the triangle test is straight-line code that every lane of the
+    // step runs twice (under "is a triangle" / "is there and is a triangle": the record that is not there reads as
+    // zeros), and the other types' tests sit behind one branch that a wave of mesh leaves never takes.  The order in
+    // which a leaf's candidates are offered does not matter (see `consider`).
+    const bool tri_a = (__float_as_uint(a2.z) & RT_PRIM_TYPE_MASK) == RT_PRIM_TRIANGLE;
+    const bool tri_b = (__float_as_uint(b2.z) & RT_PRIM_TYPE_MASK) == RT_PRIM_TRIANGLE;
+    if (__builtin_amdgcn_ballot_w64(!tri_a | (two & !tri_b) | (count > 2)) != 0) {
+        if (!tri_a) test_record_other(a0, a1, a2, first, tr.ray, tr.inv, t_min, t_max, best);
+        if (two & !tri_b) test_record_other(b0, b1, b2, first + 1, tr.ray, tr.inv, t_min, t_max, best);
+        for (int32_t k = 2; k < count; k += 2) {  // (no builder makes such leaves today)
+            const float4 *q = b + (size_t)(k >> 1) * RT_LEAF_BLOCK_FLOAT4S;
+            test_record(q[2], q[3], q[4], first + k, tr.ray, tr.inv, t_min, t_max, best);
+            if (k + 1 < count) test_record(q[5], q[6], q[7], first + k + 1, tr.ray, tr.inv, t_min, t_max, best);
+        }
     }
+    test_triangle(a0, a1, a2, first, tr.ray, t_min, t_max, tri_a, best);
+    test_triangle(b0, b1, b2, first + 1, tr.ray, t_min, t_max, two & tri_b, best);
     tr.best.t = open ? best.t : tr.best.t;
-    tr.best.index = open ? best.index : tr.best.index;
-    tr.best.ties = open ? best.ties : tr.best.ties;
+    tr.best.key = open ? best.key : tr.best.key;
 }
 
 }  // namespace rtd

@@ -31,7 +31,6 @@
 #include "../../include/rtcore.h"
 #include "rt_device.hpp"
 #include "rt_traverse.hpp"
-#include "rt_pool.hpp"
 #include "scene_build.hpp"
 #include "compact.hpp"
 #include "gpu_build.hpp"
@@ -164,28 +163,28 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     unsigned long long lookups = 0;  // (wave-uniform) line look-ups of the node and primitive fetches
     unsigned long long dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // leaf steps, lanes in them, node steps, lanes in them, lanes without a ray over all steps, refills (lane 0 of each wave)
     Traversal tr;
-    int32_t ray_i = -1;     // ray this lane works on, -1 = none
-    bool parked = false;    // traversal finished, result not yet written
-    bool popping = false;   // wants the next entry of its stack
+    // What the lane is doing -- at a node, at a leaf, taking the next stack entry, finished with its result not yet
+    // written (parked), without a ray (empty) -- is ONE register, so every question the wave asks of its lanes is one
+    // compare whose result is the lane mask.
+    uint32_t state = kEmpty;
+    int32_t ray_i = 0;                       // ray this lane works on (state < kEmpty)
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: the reserved run of ray indices
     bool no_more = false;                    // wave-uniform: the global counter ran past n
+    auto lanes = [](bool p) { return (unsigned long long)__builtin_amdgcn_ballot_w64(p); };
 
     const long long loop_t0 = COUNT ? clock64() : 0;
     for (;;) {
-        const unsigned long long parked_mask = __ballot(parked);
-        const unsigned long long idle_mask = __ballot(parked || ray_i < 0);
-        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-        if (n_idle >= kServiceLanes && (parked_mask != 0ull || !no_more)) {
+        const uint32_t n_idle = (uint32_t)__popcll(lanes(state >= kParked));
+        if (n_idle >= kServiceLanes && (!no_more || lanes(state == kParked) != 0ull)) {
             if (COUNT && lane == 0) dbg[5]++;
             const long long svc_t0 = COUNT ? clock64() : 0;
-            if (parked) {
-                hit[ray_i] = make_float2(tr.best.t, __int_as_float(tr.best.index));
-                parked = false;
-                ray_i = -1;
+            if (state == kParked) {
+                hit[ray_i] = make_float2(tr.best.t, __int_as_float(tr.best.index()));
+                state = kEmpty;
             }
             // refill; rays that miss the root box (or are NaN) are answered on the spot, so repeat
             while (!no_more) {
-                const unsigned long long empty_mask = __ballot(ray_i < 0);
+                const unsigned long long empty_mask = lanes(state == kEmpty);
                 const uint32_t want = (uint32_t)__popcll(empty_mask);
                 if (want < kServiceLanes) break;
                 if (chunk_next == chunk_end) {
@@ -201,7 +200,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
                 }
                 const uint32_t avail = chunk_end - chunk_next;
                 const uint32_t give = want < avail ? want : avail;
-                if (ray_i < 0) {
+                if (state == kEmpty) {
                     // empty lanes below this one
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(empty_mask >> 32),
                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)empty_mask, 0u));
@@ -212,6 +211,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
                         tr.ray.d = f3(d4.x, d4.y, d4.z);
                         if (traversal_begin<COUNT>(sc, tr, st, t_min, t_max, &visits)) {
                             ray_i = (int32_t)i;
+                            state = kAtNode;  // node 0
                         } else {
                             hit[i] = make_float2(0.0f, __int_as_float(-1));
                         }
@@ -223,13 +223,11 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         }
         // One step for part of the wave: lanes at a node and lanes at a leaf need different code,
         // so each iteration runs only the kind that more lanes are waiting for; the others wait.
-        const bool active = ray_i >= 0 && !parked && !popping;
-        const bool at_leaf = active && (tr.entry & RT_CHILD_LEAF) != 0u;
-        const bool at_node = active && !at_leaf;
-        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
-        const uint32_t n_node = (uint32_t)__popcll(__ballot(at_node));
-        if (n_leaf + n_node == 0u && __ballot(popping) == 0ull) {
-            if (no_more && __ballot(parked) == 0ull) break;
+        const bool at_leaf = state == kAtLeaf, at_node = state == kAtNode;
+        const uint32_t n_leaf = (uint32_t)__popcll(lanes(at_leaf));
+        const uint32_t n_node = (uint32_t)__popcll(lanes(at_node));
+        if (n_leaf + n_node == 0u && lanes(state == kPopping) == 0ull) {
+            if (no_more && lanes(state == kParked) == 0ull) break;
             continue;
         }
         // The kind with the (weighted) majority runs.
@@ -252,21 +250,24 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
                 lk += 5u * wave_distinct(at_leaf, tr.entry & RT_LEAF_FIRST_MASK) + 3u * wave_distinct(at_leaf && two, tr.entry & RT_LEAF_FIRST_MASK);
             }
             if (!COMPACT && run_leaf && n_leaf) {
-                const uint32_t byte0 = (tr.entry & RT_LEAF_FIRST_MASK) * (RT_PRIM_FLOAT4S * 16u);
+                // 16-byte word index of the leaf's first record (48 bytes a record): the line of word w is w >> 3
+                const uint32_t word0 = (tr.entry & RT_LEAF_FIRST_MASK) * RT_PRIM_FLOAT4S;
                 const bool two = ((tr.entry >> 28) & 7u) != 0u;
-                for (uint32_t k = 0; k < 6u; k++) lk += wave_distinct(at_leaf && (k < 3u || two), (byte0 + 16u * k) >> 7);
+                for (uint32_t k = 0; k < 6u; k++) lk += wave_distinct(at_leaf && (k < 3u || two), (word0 + k) >> 3);
             }
             lookups += lk;
         }
-        if (run_leaf && at_leaf) {
-            if (COMPACT)
-                traversal_guarded_leaf_step<COUNT>(sc, tr, t_min, t_max, &tests);
-            else
-                traversal_leaf_step<COUNT>(sc, tr, t_min, t_max, &tests);
-            popping = true;
+        if (run_leaf) {
+            if (at_leaf) {
+                if (COMPACT)
+                    traversal_guarded_leaf_step<COUNT>(sc, tr, t_min, t_max, &tests);
+                else
+                    traversal_leaf_step<COUNT>(sc, tr, t_min, t_max, &tests);
+                state = kPopping;
+            }
+        } else if (at_node) {
+            state = COMPACT ? traversal_qnode_step<COUNT>(sc, tr, st, t_min, &visits) : traversal_node_step<COUNT>(sc, tr, st, t_min, &visits);
         }
-        if (run_node && at_node)
-            popping = COMPACT ? traversal_qnode_step<COUNT>(sc, tr, st, t_min, &visits) : traversal_node_step<COUNT>(sc, tr, st, t_min, &visits);
         // Next entry for the lanes that want one.  After a hit most of a ray's stack is beyond the
         // best distance and is dropped entry by entry; a wave waits for its slowest lane (an unbounded
         // loop here took 5.1 turns per leaf step and 1.5 per node step), so each step is followed by
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
         // with it on the wave's next turns (it takes no part in the steps meanwhile).
 #pragma unroll
         for (int turn = 0; turn < kPopTurns; turn++)
-            if (popping) popping = traversal_pop_turn(tr, st, parked);
+            if (state == kPopping) state = traversal_pop_turn(tr, st);
     }
     if (COUNT) {
         atomicAdd(&counters[0], (unsigned long long)visits);
@@ -284,44 +285,6 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
             dbg[7] = (unsigned long long)(clock64() - loop_t0);
             for (int k = 0; k < 8; k++) atomicAdd(&counters[2 + k], dbg[k]);
             atomicAdd(&counters[14], lookups);
-        }
-    }
-}
-
-// The pooled form of the extend stage (rt_pool.hpp): one wave per block, its pool of rays in LDS.
-#ifndef RT_POOL_WAVES
-#define RT_POOL_WAVES 2
-#endif
-template <bool COUNT>
-__global__ void __launch_bounds__(64, RT_POOL_WAVES)
-    extend_pool_kernel(RtSceneView sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
-                       const uint32_t *__restrict__ count_ptr, uint32_t n_fixed, float t_min, float t_max,
-                       float2 *__restrict__ hit, uint2 *ovf, uint32_t *head, unsigned long long *counters) {
-    __shared__ PoolLds L;
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t i = lane; i < kPoolSlots; i += 64u) L.q[Q_FREE][i] = (uint8_t)i;
-    PoolWave<COUNT> w(L, sc);
-    for (int k = 0; k < 4; k++) w.Q.tail[k] = 0u, w.Q.count[k] = 0u;
-    w.Q.tail[Q_FREE] = kPoolSlots, w.Q.count[Q_FREE] = kPoolSlots;
-    w.ro = ro, w.rd = rd, w.hit = hit, w.head = head;
-    w.n_rays = count_ptr ? *count_ptr : n_fixed;
-    w.t_min = t_min, w.t_max = t_max, w.lane = lane;
-    w.chunk_next = 0u, w.chunk_end = 0u, w.no_more = false;
-    const uint32_t deep = sc.max_stack > kPoolStack ? sc.max_stack - kPoolStack : 0u;
-    w.ovf = ovf + (size_t)blockIdx.x * deep * kPoolSlots;
-    if (COUNT) {
-        w.cnt.visits = 0u, w.cnt.tests = 0u;
-        for (int k = 0; k < 4; k++) w.cnt.steps[k] = 0ull, w.cnt.lanes[k] = 0ull;
-    }
-    w.run();
-    if (COUNT) {
-        atomicAdd(&counters[0], (unsigned long long)w.cnt.visits);
-        atomicAdd(&counters[1], (unsigned long long)w.cnt.tests);
-        if (lane == 0) {
-            atomicAdd(&counters[2], w.cnt.steps[Q_LEAF]), atomicAdd(&counters[3], w.cnt.lanes[Q_LEAF]);
-            atomicAdd(&counters[4], w.cnt.steps[Q_NODE]), atomicAdd(&counters[5], w.cnt.lanes[Q_NODE]);
-            atomicAdd(&counters[10], w.cnt.steps[Q_POP]), atomicAdd(&counters[11], w.cnt.lanes[Q_POP]);
-            atomicAdd(&counters[12], w.cnt.steps[K_REFILL]), atomicAdd(&counters[13], w.cnt.lanes[K_REFILL]);
         }
     }
 }
@@ -401,11 +364,10 @@ __device__ __forceinline__ bool shade_path(const RtSceneView &sc, const RtDevMat
     F3 result;
     bool alive = false;
     if (__float_as_int(ha.y) >= 0) {
-        Best best{ha.x, __float_as_int(ha.y), false};
         F3 nrm;
         uint32_t mat;
         int32_t pid;
-        finish_hit(sc, ray, best, &nrm, &mat, &pid);
+        finish_hit(sc, ray, ha.x, __float_as_int(ha.y), &nrm, &mat, &pid);
         RtDevMaterial m = mats[mat];
         F3 sdir;
         F3 att = scatter(m, ray, ha.x, nrm, key, bounce, &sdir);
@@ -486,11 +448,10 @@ __global__ void __launch_bounds__(kBlock)
         ray.d = f3(d4.x, d4.y, d4.z);
         F3 result;
         if (__float_as_int(ha.y) >= 0) {
-            Best best{ha.x, __float_as_int(ha.y), false};
             F3 nrm;
             uint32_t mat;
             int32_t pid;
-            finish_hit(sc, ray, best, &nrm, &mat, &pid);
+            finish_hit(sc, ray, ha.x, __float_as_int(ha.y), &nrm, &mat, &pid);
             RtDevMaterial m = mats[mat];
             if (mode == RT_MODE_NORMALS) {
                 result = (nrm + f3(1.0f, 1.0f, 1.0f)) * 0.5f;
@@ -580,10 +541,7 @@ __global__ void __launch_bounds__(kBlock)
     F3 nrm = f3(0.0f, 0.0f, 0.0f);
     uint32_t mat = 0;
     int32_t pid = -1;
-    if (ok) {
-        Best best{ha.x, __float_as_int(ha.y), false};
-        finish_hit(sc, ray, best, &nrm, &mat, &pid);
-    }
+    if (ok) finish_hit(sc, ray, ha.x, __float_as_int(ha.y), &nrm, &mat, &pid);
     if (prim_id) prim_id[i] = pid;
     if (t) t[i] = ok ? ha.x : 0.0f;
     if (normal) {
@@ -657,8 +615,6 @@ struct RtScene {
     uint64_t work_paths = 0;
     uint64_t paths_in_flight = 0;  // default batch size, fixed at the first call that needs it
     uint32_t extend_blocks = 0;
-    bool pooled = false;         // which form of the extend stage runs (RTCORE_EXTEND=pool|wave)
-    uint32_t pool_blocks = 0;    // resident one-wave blocks of the pooled form
     bool timing = false;
     bool counting = false;
     std::vector<TimedSpan> spans;
@@ -686,9 +642,8 @@ int ensure_work(RtScene *s, uint64_t paths) {
     if (paths <= s->work_paths && s->extend_blocks) return RT_OK;
     int rc;
     for (int k = 0; k < 2; k++) {
-        // (128 spare bytes: the pooled extend stage requests seven 16-byte words from every record it touches)
-        if ((rc = s->st_o[k].ensure(paths * 16 + 128))) return rc;
-        if ((rc = s->st_d[k].ensure(paths * 16 + 128))) return rc;
+        if ((rc = s->st_o[k].ensure(paths * 16))) return rc;
+        if ((rc = s->st_d[k].ensure(paths * 16))) return rc;
         if ((rc = s->st_thr[k].ensure(paths * 16))) return rc;
     }
     if ((rc = s->hit_a.ensure(paths * 8))) return rc;
@@ -702,19 +657,9 @@ int ensure_work(RtScene *s, uint64_t paths) {
         if ((rc = s->counters.ensure(128))) return rc;
         RT_HIP(hipMemset(s->counters.p, 0, 128));
     }
-    if (s->pooled && !s->pool_blocks) {
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, extend_pool_kernel<false>, 64, 0) != hipSuccess || per_cu < 1)
-            per_cu = 4;
-        s->pool_blocks = (uint32_t)s->n_cus * (uint32_t)per_cu;
-    }
     if (!s->extend_blocks) s->extend_blocks = resident_extend_blocks(s->n_cus, s->compact);
     uint32_t deep = s->view.max_stack > RT_LDS_STACK ? s->view.max_stack - RT_LDS_STACK : 0;
     size_t ovf_bytes = (size_t)deep * s->extend_blocks * kBlock * sizeof(uint2);
-    if (s->pooled) {
-        const uint32_t pdeep = s->view.max_stack > kPoolStack ? s->view.max_stack - kPoolStack : 0;
-        ovf_bytes = std::max(ovf_bytes, (size_t)pdeep * s->pool_blocks * kPoolSlots * sizeof(uint2));
-    }
     if (ovf_bytes) {
         if ((rc = s->ovf.ensure(ovf_bytes))) return rc;
     }
@@ -760,17 +705,6 @@ int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4
     if (n_upper == 0) return RT_OK;
     uint32_t blocks = std::min(blocks_for(n_upper), s->extend_blocks);
     StageTimer tm(s, stream, 0);
-    if (s->pooled) {
-        const uint32_t pblocks = std::min((n_upper + 63u) / 64u, s->pool_blocks);
-        if (counted)
-            hipLaunchKernelGGL(extend_pool_kernel<true>, dim3(pblocks), dim3(64), 0, stream, s->view, ro, rd, count_ptr, n_upper,
-                               t_min, t_max, (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head, (unsigned long long *)s->counters.p);
-        else
-            hipLaunchKernelGGL(extend_pool_kernel<false>, dim3(pblocks), dim3(64), 0, stream, s->view, ro, rd, count_ptr, n_upper,
-                               t_min, t_max, (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head, (unsigned long long *)s->counters.p);
-        RT_HIP(hipGetLastError());
-        return RT_OK;
-    }
     auto kernel = counted ? (s->compact ? extend_kernel<true, true> : extend_kernel<true, false>)
                           : (s->compact ? extend_kernel<false, true> : extend_kernel<false, false>);
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr, n_upper, t_min, t_max,
@@ -940,7 +874,13 @@ extern "C" int rt_set_error_message(int code, const char *msg) { return fail(cod
 extern "C" {
 
 const char *rt_last_error(void) { return g_error.c_str(); }
-const char *rt_version(void) { return "rtcore-mi355x 0.1 (gfx950)"; }
+const char *rt_version(void) {
+#ifdef RTCORE_EXPERIMENTS
+    return "rtcore-mi355x 0.3 (gfx950) +experiments";
+#else
+    return "rtcore-mi355x 0.3 (gfx950)";
+#endif
+}
 
 int rt_init(int device) {
     int n = 0;
@@ -970,11 +910,10 @@ static int upload_scene(const rtcore::HostScene &h, rtcore::DeviceBuild *dev, co
     hipDeviceProp_t prop;
     RT_HIP(hipGetDeviceProperties(&prop, s->device));
     s->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (const char *e = std::getenv("RTCORE_EXTEND")) s->pooled = std::string(e) == "pool";
-    // RTCORE_NODES=wide keeps the 128-byte nodes for the closest-hit kernel (the pooled form reads only those)
-    s->compact = !s->pooled;
-    if (const char *e = std::getenv("RTCORE_NODES")) s->compact = s->compact && std::string(e) != "wide";
-    if (peer) s->compact = peer->compact, s->pooled = peer->pooled;
+    // RTCORE_NODES=wide keeps the 128-byte nodes (exact child boxes) for the closest-hit kernel
+    s->compact = true;
+    if (const char *e = std::getenv("RTCORE_NODES")) s->compact = std::string(e) != "wide";
+    if (peer) s->compact = peer->compact;
     s->extend_blocks = resident_extend_blocks(s->n_cus, s->compact);
     int rc;
     auto upload = [&](DevBuf &b, const void *src, size_t bytes) -> int {
@@ -1139,8 +1078,10 @@ int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info) {
     info->n_wide_nodes = h.n_nodes;
     info->n_binary_nodes = h.n_binary_nodes;
     info->wide_depth = h.wide_depth;
-    // what a scene made from this build holds on the device: compact nodes, leaf blocks, the records the shading
-    // stage reads, materials, environment
+    // what rt_scene_create would hold on the device for this build under the current environment: compact nodes and
+    // leaf blocks (the default), or the 128-byte nodes and the primitive records (RTCORE_NODES=wide, or a tree whose
+    // leaf blocks a child word cannot address), plus the records the shading stage reads, materials
+    // and environment; every array carries 128 spare bytes
     uint64_t n_blocks = 0;
     for (size_t nd = 0; nd < h.n_nodes; nd++) {
         uint32_t w[4];
@@ -1148,10 +1089,15 @@ int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info) {
         for (int c = 0; c < 4; c++)
             if (w[c] != RT_CHILD_NONE && (w[c] & RT_CHILD_LEAF)) n_blocks += (((w[c] >> 28) & 7u) + 2u) >> 1;
     }
-    info->node_bytes = RT_QNODE_FLOAT4S * 16;
+    bool compact = true;
+    if (const char *e = std::getenv("RTCORE_NODES")) compact = std::string(e) != "wide";
+    if (n_blocks > (uint64_t)RT_LEAF_FIRST_MASK) compact = false;
+    auto padded = [](uint64_t bytes) { return bytes ? bytes + 128 : 0; };
+    info->node_bytes = (compact ? RT_QNODE_FLOAT4S : RT_NODE_FLOAT4S) * 16;
     info->primitive_bytes = RT_PRIM_FLOAT4S * 16;
-    info->device_bytes = h.n_nodes * (RT_QNODE_FLOAT4S * 16) + n_blocks * (RT_LEAF_BLOCK_FLOAT4S * 16) +
-                         (h.shade_records.size() + h.env.size()) * 4 + h.materials.size() * sizeof(RtDevMaterial);
+    info->device_bytes = (compact ? padded(h.n_nodes * (uint64_t)(RT_QNODE_FLOAT4S * 16)) + padded(n_blocks * (uint64_t)(RT_LEAF_BLOCK_FLOAT4S * 16))
+                                  : padded(h.n_nodes * (uint64_t)(RT_NODE_FLOAT4S * 16)) + padded(h.n_prims * (uint64_t)(RT_PRIM_FLOAT4S * 16))) +
+                         padded(h.shade_records.size() * 4) + padded(h.env.size() * 4) + padded(h.materials.size() * sizeof(RtDevMaterial));
     info->builder = RT_BUILD_EXACT;
     for (int k = 0; k < 3; k++) info->bounds_min[k] = h.root_lo[k], info->bounds_max[k] = h.root_hi[k];
     return RT_OK;
@@ -1225,9 +1171,6 @@ int rt_scene_stats(const RtScene *cs, RtStats *out) {
                          (double)c[6] / (double)(c[2] + c[4]), c[7]),
             std::fprintf(stderr, "[rtcore] refills take %.1f %% of the waves' time, %.0f clocks each\n",
                          100.0 * (double)c[8] / (double)(c[9] ? c[9] : 1), (double)c[8] / (double)(c[7] ? c[7] : 1));
-        if (std::getenv("RTCORE_DEBUG_STEPS") && c[10] + c[12])
-            std::fprintf(stderr, "[rtcore] pool: pop steps %llu with %.1f lanes, refill steps %llu with %.1f lanes\n", c[10],
-                         c[10] ? (double)c[11] / (double)c[10] : 0.0, c[12], c[12] ? (double)c[13] / (double)c[12] : 0.0);
         RT_HIP(hipMemset(s->counters.p, 0, 128));
     }
     *out = s->stats;

@@ -1088,11 +1088,11 @@ int build_host_scene(const RtSceneDesc *d, HostScene &hs, std::string &err) {
         // tessellated meshes traverses as well as the SAH rebuild: 21.4 vs 24.7 node visits per ray on
         // the 1 M-triangle bench scene).  RTCORE_INTERIOR=sah selects the rebuild; results are
         // identical either way, only the number of box tests differs.
-        const char *interior = std::getenv("RTCORE_INTERIOR");
+        const char *interior = experiment_env("RTCORE_INTERIOR");
         if (!(interior && std::strcmp(interior, "sah") == 0)) {
             Collapser C(B.nodes, rank_of);
             // RTCORE_COLLAPSE=greedy keeps the simpler rule (dissolve the child with the largest box first)
-            const char *collapse = std::getenv("RTCORE_COLLAPSE");
+            const char *collapse = experiment_env("RTCORE_COLLAPSE");
             const bool greedy = collapse && std::strcmp(collapse, "greedy") == 0;
             if (!greedy) {
                 // the table of every subtree, side by side, then of the top of the tree

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <cstdlib>
 #include <string>
 #include <utility>
 #include <vector>
@@ -60,6 +61,20 @@ void mesh_rotor(const RtMesh &m, float rot[4]);
 
 // Camera::new (src/camera.rs:21-50)
 void make_camera(const RtCamera &c, float aspect, RtDevCamera &out);
+
+// The tree shapes that were measured against the default and lost -- a rebuilt (surface-area) interior, the greedy
+// 4-wide collapse, the Morton-order tree of the device build -- answer to their environment switches only in a library
+// built with -DRTCORE_EXPERIMENTS (`make experiments`: librtcore_experiments.so, which the tests that check them load
+// through RTCORE_LIB).  In the shipped library the switches read as unset, so one tree shape per builder is all that
+// every kernel change has to keep exact.
+inline const char *experiment_env(const char *name) {
+#ifdef RTCORE_EXPERIMENTS
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 }  // namespace rtcore
 #endif

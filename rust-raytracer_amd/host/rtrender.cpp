@@ -9,6 +9,7 @@
 // written when the passes are done (the reference writes output/<unix millis>.png on Enter).
 // --gpus N renders passes round-robin on N devices from one process (one host thread and one scene
 // replica per device, accumulators resident on the devices) and sums the accumulators once, on the devices.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -97,7 +98,11 @@ static bool parse_args(int argc, char **argv, Args &a) {
             a.scene = k;
         }
     }
-    return a.gpus >= 1;
+    if (a.gpus < 1 || a.gpus > 64) {
+        std::fprintf(stderr, "error: --gpus takes 1 to 64, got %d\n", a.gpus);
+        return false;
+    }
+    return true;
 }
 
 int main(int argc, char **argv) {
@@ -162,7 +167,8 @@ int main(int argc, char **argv) {
         // With one device the reference's loop is kept (a print per pass, src/main.rs:259-278); with several the
         // passes run concurrently and are summed once, so there is one print per round of `gpus` passes at most:
         // --sync-every N sums and reports every N rounds (0 = once, at the end).
-        const uint32_t per_round = (uint32_t)args.gpus * (args.gpus > 1 ? (args.sync_every ? args.sync_every : args.passes) : 1u);
+        const uint64_t per_round64 = (uint64_t)args.gpus * (args.gpus > 1 ? (args.sync_every ? args.sync_every : args.passes) : 1u);
+        const uint32_t per_round = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_round64, args.passes));
         for (uint32_t pass = 0; pass < args.passes; pass += per_round) {
             std::printf("rendering...\n");
             const uint32_t count = std::min<uint32_t>(per_round, args.passes - pass);

@@ -197,12 +197,12 @@ def sky_map(width=2048, height=1024, sun_dir=(0.4, 0.7, -0.6), sun_radiance=50.0
 def teaset(fixture=None, env_size=(2048, 1024)):
     """The reference's tea-set scene (values of scene/example/teapot.ron): four OBJ files = eight tobj models
     (17,228 triangles) on a table, ceramic / glass / steel, lit by an environment map.  The meshes come from
-    tests/golden/teaset.npz (made by tools/make_teaset_fixture.py from the reference's OBJ data); the HDR the scene
+    the package's data/teaset.npz (made by tools/make_teaset_fixture.py from the reference's OBJ data); the HDR the scene
     names is not distributable, so a procedural sky stands in (sky_map)."""
     import os
 
     if fixture is None:
-        fixture = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "teaset.npz")
+        fixture = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "teaset.npz")
     z = np.load(fixture)
     s = SceneDescription()
     s.set_camera(eye=(-0.5, 1.3, -3.0), lookat=(0.2, 1.0, 0.0), fov=50.0, focus_dist=3.0, aperture=0.1)
@@ -229,16 +229,12 @@ def teaset(fixture=None, env_size=(2048, 1024)):
 def sky_environment(width, height):
     """The procedural sky as the renderer gets it from a scene file's `hdr:` entry: written as a Radiance .hdr and read
     back through the C++ host's RGBE reader (src/io.rs:106-111 reads the file with the radiant crate), i.e. with the
-    values a real .hdr can hold.  512 x 256 comes from the committed fixture tests/golden/sky_512x256_flat.hdr; other
-    sizes are generated, written to a temporary file and read back the same way."""
+    values a real .hdr can hold: generated, written to a temporary file (run-length scanlines) and read back."""
     import os
     import tempfile
 
     from . import hostio
 
-    golden = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sky_512x256_flat.hdr")
-    if (width, height) == (512, 256) and os.path.exists(golden):
-        return hostio.load_hdr(golden)
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "sky.hdr")
         hostio.save_hdr(path, sky_map(width, height), rle=True)

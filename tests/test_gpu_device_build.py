@@ -113,6 +113,8 @@ def test_coincident_twins_differ_only_in_which_twin_is_named(pkg, oracle):
 def test_morton_order_tree_gives_the_same_hits(pkg, oracle, monkeypatch):
     """RTCORE_DEVICE_TREE=morton: the other binary tree of the device build (Morton codes, radix sort, binary radix
     tree).  Same records and guard boxes, so the same hits; only the number of box tests differs."""
+    if b"+experiments" not in pkg.load().rt_version():
+        pytest.skip("the Morton-order tree is compiled only into `make experiments` builds (load one through RTCORE_LIB)")
     monkeypatch.setenv("RTCORE_DEVICE_TREE", "morton")
     d = pkg.scenes.mesh_scene(n_triangles=100_000, rings=24, segments=24, seed=11)
     mn, mx = oracle.OracleScene(d).bounds()

@@ -152,3 +152,87 @@ def test_headline_10m_triangle_4k_pass_and_rays_match_oracle(pkg, oracle):
     assert np.array_equal(dnrm[same].view(np.uint32), onrm[same].view(np.uint32))
     print("10 M triangles built on the GPU in %.0f ms: %d of %d rays name the other triangle of an exact tie"
           % (dev.info().build_ms, named_other, len(rays)))
+
+
+def _uniform_rays(n, info, seed, inflate=1.5):
+    """n rays on the device: origins uniform in the scene's box scaled by `inflate`, directions uniform on the sphere."""
+    import math
+    import torch
+
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    mn, mx = np.array(info.bounds_min[:]), np.array(info.bounds_max[:])
+    c = torch.tensor((mn + mx) / 2, device="cuda", dtype=torch.float32)
+    h = torch.tensor((mx - mn) / 2 * inflate, device="cuda", dtype=torch.float32)
+    rays = torch.empty((n, 6), dtype=torch.float32, device="cuda")
+    rays[:, 0:3] = c + (torch.rand((n, 3), device="cuda", generator=g) * 2 - 1) * h
+    z = torch.rand(n, device="cuda", generator=g) * 2 - 1
+    ph = torch.rand(n, device="cuda", generator=g) * (2 * math.pi)
+    rr = torch.sqrt(torch.clamp(1 - z * z, min=0))
+    rays[:, 3], rays[:, 4], rays[:, 5] = rr * torch.cos(ph), rr * torch.sin(ph), z
+    return rays
+
+
+def _scene_with_exact_boxes(pkg, d, monkeypatch):
+    """The same scene walked over the 128-byte nodes: every child box exact, the reference's box test
+    (/root/reference/src/tracer/cube.rs:163-171) applied to each verbatim.  That form is itself checked against the
+    oracle (tests/test_gpu_compact_nodes.py), so whatever equals it is checked against the oracle through it."""
+    monkeypatch.setenv("RTCORE_NODES", "wide")
+    scene = pkg.Scene(d)
+    monkeypatch.delenv("RTCORE_NODES")
+    assert scene.info().node_bytes == 128
+    return scene
+
+
+@pytest.mark.timeout(900)
+def test_whole_100m_ray_batch_equals_the_exact_box_form(pkg, monkeypatch):
+    """Every one of the 100 M rays of the closest-hit configuration (1 M triangles), and 100 M more that start among the
+    meshes, through the default library (compact nodes, guard boxes) and through the exact-box form: all ids and all t
+    equal.  Extends the oracle's reach from its 1 M-ray subsample to the whole batch the bench times."""
+    import torch
+
+    d = pkg.scenes.mesh_scene(n_triangles=1_000_000, seed=7)
+    compact = pkg.Scene(d)
+    assert compact.info().node_bytes == 64
+    wide = _scene_with_exact_boxes(pkg, d, monkeypatch)
+    n = 100_000_000
+    stream = torch.cuda.current_stream().cuda_stream
+    ids = [torch.empty(n, dtype=torch.int32, device="cuda") for _ in range(2)]
+    t = [torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(2)]
+    for seed, inflate in ((0x5EED, 1.5), (0x5EEE, 0.7)):
+        rays = _uniform_rays(n, compact.info(), seed, inflate)
+        for k, scene in enumerate((compact, wide)):
+            scene.closest_hit_device(rays.data_ptr(), n, ids[k].data_ptr(), t[k].data_ptr(), None, None, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(ids[0], ids[1]), int((ids[0] != ids[1]).sum())
+        assert torch.equal(t[0].view(torch.int32), t[1].view(torch.int32))
+        crc = [zlib.crc32(x[:20_000_000].cpu().numpy().tobytes()) for x in ids]
+        assert crc[0] == crc[1]
+        assert 0.2 < float((ids[0] >= 0).float().mean()) <= 1.0
+        del rays
+
+
+@pytest.mark.timeout(1500)
+def test_whole_headline_pass_equals_the_exact_box_form(pkg, monkeypatch):
+    """One whole pass of the default bench configuration (10 M triangles, 3840 x 2160, 16 spp, 8 bounces: 492 M rays)
+    through the default library and through the exact-box form: the two accumulators are bitwise equal, and so are the
+    ray counts.  The oracle checks four spans of this pass (test above); this carries that to every pixel."""
+    import torch
+
+    d = pkg.scenes.mesh_scene(n_triangles=10_000_000, seed=7)
+    W, H, spp, bounces = 3840, 2160, 16, 8
+    p = pkg.Scene.params(W, H, spp, bounces, pass_index=5, seed=1234)
+    stream = torch.cuda.current_stream().cuda_stream
+    frames, rays = [], []
+    for make in (lambda: pkg.Scene(d), lambda: _scene_with_exact_boxes(pkg, d, monkeypatch)):
+        scene = make()
+        accum = torch.zeros(W * H * 3, dtype=torch.float32, device="cuda")
+        scene.stats()
+        scene.render_pass_device(accum.data_ptr(), p, stream)
+        torch.cuda.synchronize()
+        rays.append(scene.stats().rays)
+        frames.append(accum)
+        scene.close()
+    assert rays[0] == rays[1] and rays[0] > W * H * spp
+    assert torch.equal(frames[0].view(torch.int32), frames[1].view(torch.int32)), int((frames[0] != frames[1]).sum())
+    assert bool(torch.isfinite(frames[0]).all()) and float(frames[0].max()) > 0.0

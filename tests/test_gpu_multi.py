@@ -93,3 +93,75 @@ def test_rtrender_with_two_replicas(tmp_path, pkg):
     # two replicas add the passes in another order: the 8-bit frames may differ in a last bit here and there
     a, b = np.frombuffer(outs[0], np.uint8), np.frombuffer(outs[1], np.uint8)
     assert len(a) == len(b) and (a != b).mean() < 0.01
+
+
+def test_rccl_reduce_runs_on_one_device(pkg):
+    """rt_reduce(how = RCCL) with a single distinct device goes through ncclCommInitAll and a grouped in-place
+    ncclReduce (a one-rank communicator): the buffer comes back unchanged and the handle reports the RCCL path.  This
+    is as far as the library's one-process RCCL code can run on one GPU; more ranks are the 8-GPU node's."""
+    import torch
+
+    lib = pkg.load()
+    assert lib.rt_comm_available() == 1
+    multi = pkg.MultiScene(pkg.scenes.cornell(), [0])
+    n = 3840 * 2160 * 3  # the 4K accumulator
+    a = torch.rand(n, dtype=torch.float32, device="cuda")
+    before = a.clone()
+    torch.cuda.synchronize()
+    multi.reduce([a.data_ptr()], n, how=0)  # auto: one replica, nothing to do
+    assert multi.last_reduce() == "none"
+    multi.reduce([a.data_ptr()], n, how=1)
+    assert multi.last_reduce() == "rccl"
+    multi.reduce([a.data_ptr()], n, how=1)  # the communicator is kept between calls
+    torch.cuda.synchronize()
+    assert torch.equal(a, before)
+    multi.close()
+
+
+def test_without_rccl_the_sum_takes_peer_copies_and_nothing_crashes():
+    """A machine without librccl (every dlopen fails: RTCORE_RCCL_LIB names a file that is not there): the library
+    loads, says why RCCL is not usable, sums by peer copies when left the choice, refuses an explicit RCCL request, and
+    tears everything down.  Own process: the library looks RCCL up once."""
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package()
+lib = pkg.load()
+import ctypes as C
+assert lib.rt_comm_available() == 0
+ident = (C.c_ubyte * 128)()
+assert lib.rt_comm_unique_id(ident) != 0
+msg = lib.rt_last_error().decode()
+assert "librccl not found" in msg and "no/such" in msg, msg
+d = pkg.scenes.cornell()
+W, H, spp = 64, 48, 2
+multi = pkg.MultiScene(d, [0, 0])
+acc = np.zeros(W * H * 3, np.float32)
+multi.render_passes(acc, pkg.Scene.params(W, H, spp, 8, seed=4), 0, 4)
+assert multi.last_reduce() == "peer"
+scene = pkg.Scene(d)
+want = np.zeros_like(acc)
+parts = []
+for g in range(2):
+    p = np.zeros_like(acc)
+    for i in range(g, 4, 2):
+        scene.render_pass(p, pkg.Scene.params(W, H, spp, 8, pass_index=i, seed=4))
+    parts.append(p)
+assert np.array_equal(acc.view(np.uint32), (parts[0] + parts[1]).view(np.uint32))
+import torch
+a = torch.ones(1000, device="cuda"); b = torch.ones(1000, device="cuda")
+try:
+    multi.reduce([a.data_ptr(), b.data_ptr()], 1000, how=1)
+    raise SystemExit("an explicit RCCL request must fail")
+except pkg.RtError as e:
+    pass
+multi.close()
+single = pkg.MultiScene(d, [0])
+single.close()
+print("ok")
+''' % ROOT
+    env = dict(os.environ, RTCORE_RCCL_LIB="/no/such/librccl.so")
+    out = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

@@ -329,25 +329,3 @@ def test_preview_of_a_pixel_range_leaves_the_rest_untouched(pkg, oracle):
         inside[3 * first:3 * (first + count)] = True
         assert np.all(buf[~inside] == np.float32(-7.25))
         assert np.array_equal(buf[inside].view(np.uint32), whole[inside].view(np.uint32))
-
-
-def test_pooled_extend_stage_gives_the_same_bits(pkg, oracle, monkeypatch):
-    """RTCORE_EXTEND=pool selects the other form of the closest-hit stage (a pool of rays per wave in LDS, steps
-    taken by queue): same hit records and same pass, bit for bit; deep stacks go through its overflow area."""
-    monkeypatch.setenv("RTCORE_EXTEND", "pool")
-    d = pkg.scenes.mesh_scene(n_triangles=150_000, rings=32, segments=32, seed=9)
-    scene = pkg.Scene(d)
-    monkeypatch.delenv("RTCORE_EXTEND")
-    ora = oracle.OracleScene(d)
-    rays = pkg.scenes.random_rays(300_000, *ora.bounds(), seed=12, inflate=0.8)
-    rays[7] = 0.0
-    ids, t, nrm, pt = scene.closest_hit(rays)
-    oids, ot, onrm, opt = ora.closest_hit(rays)
-    assert np.array_equal(ids, oids) and np.array_equal(t.view(np.uint32), ot.view(np.uint32))
-    assert np.array_equal(nrm.view(np.uint32), onrm.view(np.uint32)) and np.array_equal(pt.view(np.uint32), opt.view(np.uint32))
-    W, H = 96, 64
-    p = pkg.Scene.params(W, H, 6, 8, seed=77)
-    acc, oacc = np.zeros(W * H * 3, np.float32), np.zeros(W * H * 3, np.float32)
-    scene.render_pass(acc, p)
-    ora.render_pass(oacc, p)
-    assert np.array_equal(acc.view(np.uint32), oacc.view(np.uint32))

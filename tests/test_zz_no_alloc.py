@@ -58,3 +58,55 @@ def test_noalloc_closest_hit_matches_the_allocating_entry_point(pkg):
     with pytest.raises(pkg.RtError) as e:
         scene.closest_hit_noalloc_device(rays.data_ptr(), pkg._abi.RT_NOALLOC_MAX_RAYS + 1, ids.data_ptr(), None, None, None, 0)
     assert "at most" in str(e.value)
+
+
+def _chain_scene(pkg, n=200):
+    """Spheres whose centres grow geometrically along x: the reference's middle split (src/tracer/bvh.rs:106-117) peels
+    them off one or two at a time, so the tree is about as deep as it is large."""
+    s = pkg.scene.SceneDescription()
+    s.set_camera(eye=(-5.0, 0.0, 0.0), lookat=(0.0, 0.0, 0.0), fov=40.0, focus_dist=5.0, aperture=0.0)
+    m = s.add_material(pkg.scene.lambertian((0.6, 0.6, 0.6)))
+    for k in range(n):
+        x = 1.5 ** k
+        s.add_sphere((x, 0.0, 0.0), 0.2 * x, m)
+    return s
+
+
+def test_noalloc_deep_tree_shrinks_the_grid_and_allocates_nothing(pkg, monkeypatch):
+    """A tree deep enough that the traversal stacks' overflow area for a full grid would not fit in the work array (the
+    entry point then launches fewer blocks), through both node forms; the device's free memory does not move across
+    the calls (no hipMalloc / hipFree behind them)."""
+    import torch
+
+    lib = pkg.load()
+    pkg._abi.check(lib.rt_init(0))
+    d = _chain_scene(pkg)
+    scenes = [pkg.Scene(d)]
+    monkeypatch.setenv("RTCORE_NODES", "wide")
+    scenes.append(pkg.Scene(d))
+    monkeypatch.delenv("RTCORE_NODES")
+    assert [s.info().node_bytes for s in scenes] == [64, 128]
+    # 3 stack entries per level + 4, 11 of them in LDS, 2 KiB per entry and block: beyond 27 entries a grid of
+    # 7 blocks on each of 256 CUs no longer fits in the 53 MiB the work array leaves for it
+    assert scenes[0].info().wide_depth >= 40
+    n = 100_000
+    rng = np.random.default_rng(5)
+    rays = np.zeros((n, 6), np.float32)
+    rays[:, 0] = -5.0
+    rays[:, 1:3] = rng.uniform(-0.3, 0.3, (n, 2))
+    rays[:, 3] = 1.0
+    rays[:, 4:6] = rng.uniform(-0.05, 0.05, (n, 2))
+    d_rays = torch.from_numpy(rays).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+    out = [[torch.empty(n, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.float32, device="cuda")] for _ in range(3)]
+    scenes[0].closest_hit_device(d_rays.data_ptr(), n, out[0][0].data_ptr(), out[0][1].data_ptr(), None, None, stream)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    for k, scene in enumerate(scenes):
+        scene.closest_hit_noalloc_device(d_rays.data_ptr(), n, out[1 + k][0].data_ptr(), out[1 + k][1].data_ptr(), None, None, stream)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
+    for k in (1, 2):
+        assert torch.equal(out[0][0], out[k][0])
+        assert torch.equal(out[0][1].view(torch.int32), out[k][1].view(torch.int32))
+    assert int((out[0][0] >= 0).sum()) > n // 2

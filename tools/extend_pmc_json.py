@@ -19,7 +19,7 @@ from srchash import kernel_source_hash  # noqa: E402
 
 d = sys.argv[1]
 out_path = sys.argv[2]
-KERNELS = {"extend": "extend_kernel<false", "extend_pool": "extend_pool_kernel<false>", "shade": "shade_kernel"}
+KERNELS = {"extend": "extend_kernel<false", "shade": "shade_kernel"}
 
 
 def rows(pattern):
@@ -45,6 +45,11 @@ def summarise(name):
     for r in trace:
         if name in r["Kernel_Name"]:
             res["vgpr"], res["sgpr"], res["lds_bytes"] = r.get("VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size")
+            try:
+                # 256-thread blocks (one wave per SIMD each): as many per CU as the 160 KiB of LDS hold, 8 at most
+                res["waves_per_simd"] = min(8, 163840 // max(1, int(res["lds_bytes"]))) if int(res["lds_bytes"]) else 8
+            except (TypeError, ValueError):
+                pass
             break
     if cnt.get("FETCH_SIZE"):
         res["hbm_bytes_per_launch_raw"] = sums["FETCH_SIZE"] * 1024.0 / cnt["FETCH_SIZE"]
@@ -67,7 +72,9 @@ def summarise(name):
     return res
 
 
-out = {"source_hash": kernel_source_hash(), "git_head": os.environ.get("RT_GIT_HEAD", "")}
+out = {"source_hash": kernel_source_hash()}
+if os.environ.get("RT_GIT_HEAD"):
+    out["git_head"] = os.environ["RT_GIT_HEAD"]
 args_file = os.path.join(d, "bench_args.txt")
 if os.path.exists(args_file):
     out["bench_args"] = open(args_file).read().strip()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Builds tests/golden/teaset.npz from the reference's OBJ data files
+"""Builds rust-raytracer_amd/data/teaset.npz from the reference's OBJ data files
 (scene/models/newell_teaset/*.obj, the Newell tea set).  Run in the container that has
 /root/reference; the GPU box only sees the committed .npz.  The fixture holds, per tobj
 model, the unified positions / normals / indices exactly as objio.load returns them."""
@@ -23,6 +23,6 @@ for name in ("teapot", "teacup", "cup", "spoon"):
         out["%s_%d_normals" % (name, i)] = m["normals"]
         out["%s_%d_indices" % (name, i)] = m["indices"]
     print(name, len(models), "models", sum(len(m["indices"]) for m in models), "triangles")
-path = os.path.join(ROOT, "tests", "golden", "teaset.npz")
+path = os.path.join(ROOT, "rust-raytracer_amd", "data", "teaset.npz")
 np.savez_compressed(path, **out)
 print("wrote", path, os.path.getsize(path), "bytes")

@@ -9,8 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def kernel_source_hash():
     h = hashlib.sha256()
     files = sorted(glob.glob(os.path.join(ROOT, "rust-raytracer_amd", "csrc", "*")))
+    files.append(os.path.join(ROOT, "rust-raytracer_amd", "Makefile"))  # the compiler flags shape the code too
     for f in files:
-        if f.endswith((".hip", ".hpp", ".h", ".cpp")):
+        if f.endswith((".hip", ".hpp", ".h", ".cpp", "Makefile")):
             h.update(os.path.basename(f).encode())
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
