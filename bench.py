@@ -19,8 +19,8 @@ Prints ONE JSON line on rank 0:
                          peak = every SIMD issuing vector instructions at the ceiling rate with all 64 lanes useful,
                          achieved = vector instructions x active lanes per instruction,
                          frac = issue_frac (ceiling cycles per instruction / the kernel's) x lane utilisation.
-                         Beside it the fraction of the ceiling of a stream with the kernel's share of scalar instructions
-                         (scalar instructions take issue time too) and the share of wave-cycles spent waiting.
+                         Beside it the scalar instructions per vector instruction (they take issue time too) and the
+                         share of wave-cycles spent waiting.
                  "l1"    the CU's vector memory path (address unit TA, L1 tags TCP, data return TD), one cache-line access
                          per clock and CU: frac = TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles), TA / TD busy beside it.  This
                          bounds the kernel over the 128-byte nodes (RTCORE_NODES=wide: seven loads per node and lane).
@@ -448,11 +448,9 @@ def main():
                     "ceiling_cycles_per_vector_instruction_and_simd": ceil["cycles_per_vector_instruction"],
                     "ceiling_source": ceil["source"],
                     "scalar_per_vector_inst": round(salu_insts / valu_insts, 3),
-                    # scalar instructions take issue time too: the ceiling of a 2 : 1 vector : scalar stream (about the
-                    # kernel's ratio) and the kernel's fraction of THAT
-                    "ceiling_2_to_1_vector_scalar_stream": ceil.get("cycles_per_vector_instruction_2_to_1_scalar"),
-                    "issue_frac_of_2_to_1_stream": round(ceil["cycles_per_vector_instruction_2_to_1_scalar"] / cycles_per_valu, 4)
-                    if ceil.get("cycles_per_vector_instruction_2_to_1_scalar") else None,
+                    # scalar instructions take issue time too (a stream of two v_fma_f32 to one s_and_b64 and its no-ops
+                    # issues a vector instruction every so many cycles): context for scalar_per_vector_inst, not the ceiling
+                    "cycles_per_vector_instruction_in_a_2_to_1_vector_scalar_stream": ceil.get("cycles_per_vector_instruction_2_to_1_scalar"),
                     "rocprof_valu_busy": round(e["valu_busy_fraction"], 4),
                     "wait_any_frac_of_wave_cycles": round(e["SQ_WAIT_ANY_per_launch"] / e["SQ_WAVE_CYCLES_per_launch"], 4)
                     if e.get("SQ_WAIT_ANY_per_launch") and e.get("SQ_WAVE_CYCLES_per_launch") else None}
@@ -481,10 +479,9 @@ def main():
                               "tools/ubench/node_fetch.hip reaches with this load shape; TA / TD busy = the address and "
                               "data-return units' busy cycles / cycles (TD busy includes its waiting for the L1)"}
                 roof["l1"] = l1
-            # the unit that is busier names the bound: the instruction issue of the SIMDs (against the measured ceiling of
-            # a stream with the kernel's share of scalar instructions) or the CU's vector memory path
-            issue_busy = valu["issue_frac_of_2_to_1_stream"] or issue_frac
-            if l1 is not None and l1["frac"] > issue_busy:
+            # the busier unit names the bound: the SIMDs' vector issue (against the measured ceiling) or the CU's vector
+            # memory path (against one line access per clock)
+            if l1 is not None and l1["frac"] > issue_frac:
                 roof.update({"bound": "l1", "unit": "G line accesses/s", "achieved": l1["achieved_G_line_accesses_per_s"],
                              "peak": l1["peak_G_line_accesses_per_s"], "frac": l1["frac"]})
             else:

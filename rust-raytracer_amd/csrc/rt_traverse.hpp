@@ -27,10 +27,6 @@
 
 #include "rt_device.hpp"
 
-#ifndef RT_SORT_EXCHANGES
-#define RT_SORT_EXCHANGES 5
-#endif
-
 namespace rtd {
 
 struct Best {
@@ -606,10 +602,9 @@ RT_DEV int qnode_children_sorted(const QNodeWords &w, const F3 o, const F3 inv, 
         const uint32_t wj = sw ? cw[i] : cw[j];         \
         key[i] = ki, key[j] = kj, cw[i] = wi, cw[j] = wj; \
     }
-    RT_CSEL(0, 1) RT_CSEL(2, 3) RT_CSEL(0, 2) RT_CSEL(1, 3)
-#if RT_SORT_EXCHANGES >= 5
-    RT_CSEL(1, 2)
-#endif
+    // (all five exchanges are needed: descend relies on the hit children being the LAST pairs, which a partly
+    // sorted quadruple does not give -- the pair it would go on with could be an empty slot's)
+    RT_CSEL(0, 1) RT_CSEL(2, 3) RT_CSEL(0, 2) RT_CSEL(1, 3) RT_CSEL(1, 2)
 #undef RT_CSEL
     return nh;
 }
@@ -666,8 +661,11 @@ RT_DEV void traversal_guarded_leaf_step(const RtSceneView &sc, Traversal &tr, fl
             if (k + 1 < count) test_record(q[5], q[6], q[7], first + k + 1, tr.ray, tr.inv, t_min, t_max, best);
         }
     }
-    test_triangle(a0, a1, a2, first, tr.ray, t_min, t_max, tri_a, best);
-    test_triangle(b0, b1, b2, first + 1, tr.ray, t_min, t_max, two & tri_b, best);
+    // (and a wave whose leaves hold no triangle at all -- a scene of spheres and boxes -- skips the triangle code)
+    if (__builtin_amdgcn_ballot_w64(tri_a | (two & tri_b)) != 0) {
+        test_triangle(a0, a1, a2, first, tr.ray, t_min, t_max, tri_a, best);
+        test_triangle(b0, b1, b2, first + 1, tr.ray, t_min, t_max, two & tri_b, best);
+    }
     tr.best.t = open ? best.t : tr.best.t;
     tr.best.key = open ? best.key : tr.best.key;
 }
