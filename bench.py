@@ -12,8 +12,8 @@ Prints ONE JSON line on rank 0:
   value        Mrays/s of the whole job: Bvh::hit invocations (primary rays + every continued
                bounce) of all ranks / max-over-ranks wall time of the K steps
   roofline     closest-hit ("extend") kernel, from the rocprofv3 counter profile of this same configuration under
-               profiles/, used only while its stamp (hash of the kernel sources, bench arguments) matches this run.  Two
-               units can bound it and both are reported; `bound` names the busier one:
+               profiles/, used only while its stamp (hash of the kernel sources, bench arguments) matches this run.  Three
+               units can bound it and all are reported; `bound` names the busiest one:
                  "valu"  the vector ALU, against a MEASURED ceiling (profiles/r03_valu_rate.json: the node step's own
                          code on register-resident nodes, in-kernel cycle counter, at the kernel's waves per SIMD):
                          peak = every SIMD issuing vector instructions at the ceiling rate with all 64 lanes useful,
@@ -21,9 +21,12 @@ Prints ONE JSON line on rank 0:
                          frac = issue_frac (ceiling cycles per instruction / the kernel's) x lane utilisation.
                          Beside it the scalar instructions per vector instruction (they take issue time too) and the
                          share of wave-cycles spent waiting.
-                 "l1"    the CU's vector memory path (address unit TA, L1 tags TCP, data return TD), one cache-line access
-                         per clock and CU: frac = TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles), TA / TD busy beside it.  This
-                         bounds the kernel over the 128-byte nodes (RTCORE_NODES=wide: seven loads per node and lane).
+                 "l1"    the CU's vector memory path (address unit TA, L1 tags TCP, data return TD) serving hits: frac =
+                         TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles) / the MEASURED rate of the kernel's load shape from an
+                         L1-resident table (profiles/r03_gather_rate.json: 1.4 accesses per clock and CU), TA / TD busy beside it.
+                 "fill"  the filling of the L1's misses: 128-byte lines requested from the L2 per second against the
+                         MEASURED rates of random line fills (same table), from the L2 for the share that hits there and
+                         from beyond it for the rest.
                Without a matching profile: the line look-ups of the node and leaf fetches, counted live by the
                instrumented kernel (a lower bound of the L1's accesses).  Also reported: the HBM side (FETCH_SIZE x the
                factor calibrated on a one-line-per-lane gather, / launch time, / 8 TB/s) and the algorithmic bytes per ray
@@ -188,6 +191,22 @@ def valu_ceiling(waves_per_simd):
                           "in-kernel s_memtime cycles" % (t["node_step"]["loop_instructions"]["vector"], w)}
     return {"cycles_per_vector_instruction": 2.0, "cycles_per_vector_instruction_2_to_1_scalar": None,
             "source": "no measured table committed: 2 cycles per wave64 vector instruction (SIMD-32)"}
+
+
+def gather_ceiling():
+    """The measured rates of the CU's vector memory path for the kernel's load shape (profiles/r03_gather_rate.json, made by
+    tools/ubench/quad_fetch.hip on MI355X): per-lane 16-byte loads that hit in the L1 (accesses per clock and CU, every lane
+    active and on a line of its own), and the whole chip's rate of 128-byte line fills from the L2 and from beyond it.  One
+    access per clock and CU and no fill rates when no table is committed."""
+    path = os.path.join(ROOT, "profiles", "r03_gather_rate.json")
+    if os.path.exists(path):
+        t = json.load(open(path))
+        return {"l1_accesses_per_clk_and_cu": t["l1_hit"]["accesses_per_clk_and_cu_all_lanes"],
+                "fill_from_l2_G_per_s": t["line_fill_G_per_s"]["from_l2"],
+                "fill_beyond_l2_G_per_s": t["line_fill_G_per_s"]["beyond_l2_2GB_table"],
+                "source": "profiles/r03_gather_rate.json: four 16-byte loads per lane, every lane another node, 7 blocks per CU"}
+    return {"l1_accesses_per_clk_and_cu": 1.0, "fill_from_l2_G_per_s": None, "fill_beyond_l2_G_per_s": None,
+            "source": "no measured table committed: one line access per clock and CU"}
 
 
 def main():
@@ -395,6 +414,7 @@ def main():
         launches = max(1, int(st.extend_launches))
         key = config_key(args)
         prof = matching_profile(key)
+        gather = gather_ceiling()
         roof = {
             "kernel": "extend_kernel (closest hit)",
             "launches": launches,
@@ -413,14 +433,15 @@ def main():
             "prim_tests_per_ray": round(tests_per_ray, 2),
         }
         if extend_s > 0 and lookups_per_ray > 0:
-            # The vector L1 looks up one 128-byte line per clock and CU (tools/ubench/node_fetch.hip), and a wave's load
-            # instruction costs one look-up per DIFFERENT line among its lanes.  Look-ups of the node and leaf fetches
-            # are counted live by the instrumented kernel; ray loads, hit stores and stack overflow are not included.
-            peak = N_CU * MAX_CLOCK_GHZ
+            # A wave's load instruction costs the vector L1 one look-up per DIFFERENT line among its lanes; the peak is
+            # the measured rate of this load shape from an L1-resident table.  Look-ups of the node and leaf fetches are
+            # counted live by the instrumented kernel; ray loads, hit stores and stack overflow are not included.
+            peak = N_CU * MAX_CLOCK_GHZ * gather["l1_accesses_per_clk_and_cu"]
             achieved = st.rays * lookups_per_ray / extend_s / 1e9
             roof["l1_lookup"] = {"achieved_G_per_s": round(achieved, 1), "peak_G_per_s": round(peak, 1),
                                  "frac": round(achieved / peak, 4), "lookups_per_ray": round(lookups_per_ray, 1),
-                                 "note": "one line look-up per clock and CU; counted for node and leaf fetches only"}
+                                 "note": "%.2f line look-ups per clock and CU (%s); counted for node and leaf fetches only"
+                                         % (gather["l1_accesses_per_clk_and_cu"], gather["source"])}
         if prof is not None:
             e = prof["extend"]
             clock = e.get("clock_GHz_under_profile") or MAX_CLOCK_GHZ
@@ -464,24 +485,49 @@ def main():
                                      "note": "counters from separate rocprofv3 --pmc runs of this configuration (one run per counter group), "
                                              "not from this run"}})
             acc = e.get("TCP_TOTAL_CACHE_ACCESSES_sum_per_launch")
-            l1 = None
+            l1 = fill = None
             if acc:
                 # per-lane 16-byte gathers load the CU's vector memory path (address unit TA -> L1 tags TCP -> data
-                # return TD), which takes one cache-line access per clock
-                l1 = {"achieved_G_line_accesses_per_s": round(acc / prof_launch_s / 1e9, 1), "peak_G_line_accesses_per_s": round(N_CU * clock, 1),
-                      "frac": round(acc / cu_cycles, 4), "accesses_per_launch": int(acc),
+                # return TD); the peak is what the same load shape reaches from an L1-resident table with every lane active
+                l1_peak = gather["l1_accesses_per_clk_and_cu"]
+                l1 = {"achieved_G_line_accesses_per_s": round(acc / prof_launch_s / 1e9, 1),
+                      "peak_G_line_accesses_per_s": round(N_CU * clock * l1_peak, 1),
+                      "frac": round(acc / cu_cycles / l1_peak, 4), "accesses_per_launch": int(acc),
+                      "accesses_per_clk_and_cu": round(acc / cu_cycles, 4), "peak_accesses_per_clk_and_cu": l1_peak,
                       "ta_busy": round(e.get("TA_TA_BUSY_sum_per_launch", 0.0) / cu_cycles, 4),
                       "td_busy": round(e.get("TD_TD_BUSY_sum_per_launch", 0.0) / cu_cycles, 4),
                       "td_waiting_for_l1": round(e.get("TD_TC_STALL_sum_per_launch", 0.0) / cu_cycles, 4),
                       "ta_stalled_by_l1": round(e.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum_per_launch", 0.0) / cu_cycles, 4),
-                      "requests_to_l2_per_launch": int(e.get("TCP_TCC_READ_REQ_sum_per_launch", 0)),
-                      "note": "TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles): one line access per clock and CU is what "
-                              "tools/ubench/node_fetch.hip reaches with this load shape; TA / TD busy = the address and "
-                              "data-return units' busy cycles / cycles (TD busy includes its waiting for the L1)"}
+                      "peak_source": gather["source"],
+                      "note": "TCP_TOTAL_CACHE_ACCESSES / (CUs x cycles) against the measured rate of L1 hits; TA / TD busy = the "
+                              "address and data-return units' busy cycles / cycles (TD busy includes its waiting for the L1)"}
                 roof["l1"] = l1
-            # the busier unit names the bound: the SIMDs' vector issue (against the measured ceiling) or the CU's vector
-            # memory path (against one line access per clock)
-            if l1 is not None and l1["frac"] > issue_frac:
+                req = e.get("TCP_TCC_READ_REQ_sum_per_launch")
+                if req and gather["fill_from_l2_G_per_s"]:
+                    # the L1's misses: 128-byte lines filled from the L2 (its hit rate) or from beyond it; the peak is the
+                    # harmonic mix of the two measured fill rates at the kernel's L2 hit rate
+                    h = e.get("l2_hit_rate", 0.0)
+                    peak = 1.0 / (h / gather["fill_from_l2_G_per_s"] + (1.0 - h) / gather["fill_beyond_l2_G_per_s"])
+                    achieved = req / prof_launch_s / 1e9
+                    fill = {"achieved_G_lines_per_s": round(achieved, 1), "peak_G_lines_per_s": round(peak, 1),
+                            "frac": round(achieved / peak, 4), "requests_to_l2_per_launch": int(req), "l2_hit_rate": round(h, 4),
+                            "fill_from_l2_G_per_s": gather["fill_from_l2_G_per_s"],
+                            "fill_beyond_l2_G_per_s": gather["fill_beyond_l2_G_per_s"], "peak_source": gather["source"],
+                            "note": "L1 misses (TCP_TCC_READ_REQ, 128-byte lines) per second against the measured fill rates of "
+                                    "random lines: from the L2 for the share that hits there, from beyond it (2 GB table) for the rest"}
+                    roof["fill"] = fill
+            # the busiest unit names the bound: the SIMDs' vector issue (against the measured ceiling), the L1's hit path or
+            # the filling of its misses (against the measured gather rates)
+            cands = [("valu", issue_frac)]
+            if l1 is not None:
+                cands.append(("l1", l1["frac"]))
+            if fill is not None:
+                cands.append(("fill", fill["frac"]))
+            bound = max(cands, key=lambda c: c[1])[0]
+            if bound == "fill":
+                roof.update({"bound": "fill", "unit": "G lines/s", "achieved": fill["achieved_G_lines_per_s"],
+                             "peak": fill["peak_G_lines_per_s"], "frac": fill["frac"]})
+            elif bound == "l1":
                 roof.update({"bound": "l1", "unit": "G line accesses/s", "achieved": l1["achieved_G_line_accesses_per_s"],
                              "peak": l1["peak_G_line_accesses_per_s"], "frac": l1["frac"]})
             else:
@@ -492,7 +538,7 @@ def main():
             # (node and primitive fetches only: a lower bound of the L1's accesses)
             lk = roof.get("l1_lookup")
             roof.update({"bound": "l1", "unit": "G line accesses/s",
-                         "achieved": lk["achieved_G_per_s"] if lk else None, "peak": round(N_CU * MAX_CLOCK_GHZ, 1),
+                         "achieved": lk["achieved_G_per_s"] if lk else None, "peak": lk["peak_G_per_s"] if lk else None,
                          "frac": lk["frac"] if lk else None, "traffic": None,
                          "profile": {"file": None,
                                      "note": "no profile under profiles/ matches source hash %s and configuration '%s'; achieved is "
