@@ -171,7 +171,7 @@ RT_DEV void test_record(float4 r0, float4 r1, float4 r2, int32_t index, const Ra
 // HitRecord fields of the winning primitive (visit rank `index`, distance `t`): normal, material, primitive id.
 RT_DEV void finish_hit(const RtSceneView &sc, const Ray &ray, float t, int32_t index, F3 *normal, uint32_t *material,
                        int32_t *prim_id) {
-    const float4 *r = (const float4 *)sc.shade_records + (size_t)index * (2 * RT_PRIM_FLOAT4S);
+    const float4 *r = (const float4 *)sc.shade_records + (size_t)index * RT_SHADE_RECORD_FLOAT4S;
     float4 r0 = r[0], r1 = r[1], r2 = r[2];
     uint32_t meta = __float_as_uint(r2.z);
     uint32_t type = meta & RT_PRIM_TYPE_MASK;

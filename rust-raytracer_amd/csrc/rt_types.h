@@ -59,6 +59,12 @@
 //   abox     : w0..2 min, w3..5 max
 //   cube     : w0..2 center, w3..5 half extents, w6..9 rotor (s, xy, xz, yz)
 #define RT_PRIM_FLOAT4S 3
+/* 16-byte words from one shade record to the next.  The record itself is 2 * RT_PRIM_FLOAT4S words (96 bytes); at
+   8 words every record is one 128-byte line, so the stage that completes a hit asks for one line per path instead of
+   1.5 on average (the builders write the records back to back and the scene spreads them out). */
+#ifndef RT_SHADE_RECORD_FLOAT4S
+#define RT_SHADE_RECORD_FLOAT4S 8
+#endif
 #define RT_PRIM_TRIANGLE 0u
 #define RT_PRIM_SPHERE 1u
 #define RT_PRIM_ABOX 2u
@@ -100,8 +106,8 @@ struct RtSceneView {
     const void *qnodes;      // float4[n_nodes * 4]: the compact nodes
     const void *leaves;      // float4[n_blocks * 8]: the leaf blocks
     const void *prims;       // float4[n_prims * 3]
-    const void *shade_records; // float4[n_prims * 6]: the primitive's record and its three vertex normals side by side,
-                               // one 96-byte gather for the stage that completes a hit
+    const void *shade_records; // float4[n_prims * RT_SHADE_RECORD_FLOAT4S]: the primitive's record and its three vertex normals
+                               // side by side (96 bytes of a 128-byte line), one gather for the stage that completes a hit
     const void *materials;   // RtDevMaterial[n_materials]
     const float *env;        // rgb float triples or nullptr
     uint32_t env_w, env_h;

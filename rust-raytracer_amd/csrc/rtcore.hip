@@ -895,6 +895,14 @@ int rt_init(int device) {
     return scratch_base(cur, &base);  // the no-allocation entry point's work memory on this device
 }
 
+// Spreads the builders' back-to-back shade records out to RT_SHADE_RECORD_FLOAT4S words each.
+__global__ void __launch_bounds__(kBlock) spread_shade_records_kernel(const float4 *__restrict__ in, size_t n_words, float4 *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_words) return;
+    const size_t rec = i / (2 * RT_PRIM_FLOAT4S), w = i % (2 * RT_PRIM_FLOAT4S);
+    out[rec * RT_SHADE_RECORD_FLOAT4S + w] = in[i];
+}
+
 // Puts a built scene on the CURRENT device.  `h` keeps its arrays (several replicas may be made from one build).
 // The tree and the primitive records come from `h` (host build), from `dev` (device build on this device; the
 // scene takes the allocations over) or from `peer` (a scene on another or the same device: device-to-device copies).
@@ -963,6 +971,19 @@ static int upload_scene(const rtcore::HostScene &h, rtcore::DeviceBuild *dev, co
             s->nodes.release();
             s->prims.release();
         }
+    }
+    if (RT_SHADE_RECORD_FLOAT4S != 2 * RT_PRIM_FLOAT4S && !peer && h.n_prims) {
+        DevBuf wide;
+        if ((rc = wide.ensure((size_t)h.n_prims * RT_SHADE_RECORD_FLOAT4S * 16 + 128))) return rc;
+        RT_HIP(hipMemset(wide.p, 0, wide.bytes));
+        const size_t n_words = (size_t)h.n_prims * 2 * RT_PRIM_FLOAT4S;
+        hipLaunchKernelGGL(spread_shade_records_kernel, dim3((unsigned)((n_words + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0,
+                           (const float4 *)s->shade_records.p, n_words, (float4 *)wide.p);
+        RT_HIP(hipGetLastError());
+        RT_HIP(hipDeviceSynchronize());
+        s->shade_records.release();
+        s->shade_records.p = wide.p, s->shade_records.bytes = wide.bytes;
+        wide.p = nullptr, wide.bytes = 0;
     }
     for (const DevBuf *b : {&s->nodes, &s->qnodes, &s->leaves, &s->prims, &s->shade_records, &s->materials, &s->env})
         s->device_bytes += b->bytes;
@@ -1097,7 +1118,7 @@ int rt_scene_validate(const RtSceneDesc *desc, RtSceneInfo *info) {
     info->primitive_bytes = RT_PRIM_FLOAT4S * 16;
     info->device_bytes = (compact ? padded(h.n_nodes * (uint64_t)(RT_QNODE_FLOAT4S * 16)) + padded(n_blocks * (uint64_t)(RT_LEAF_BLOCK_FLOAT4S * 16))
                                   : padded(h.n_nodes * (uint64_t)(RT_NODE_FLOAT4S * 16)) + padded(h.n_prims * (uint64_t)(RT_PRIM_FLOAT4S * 16))) +
-                         padded(h.shade_records.size() * 4) + padded(h.env.size() * 4) + padded(h.materials.size() * sizeof(RtDevMaterial));
+                         padded(h.n_prims * (uint64_t)(RT_SHADE_RECORD_FLOAT4S * 16)) + padded(h.env.size() * 4) + padded(h.materials.size() * sizeof(RtDevMaterial));
     info->builder = RT_BUILD_EXACT;
     for (int k = 0; k < 3; k++) info->bounds_min[k] = h.root_lo[k], info->bounds_max[k] = h.root_hi[k];
     return RT_OK;
