@@ -131,6 +131,17 @@ constexpr uint32_t kRayChunk = RT_RAY_CHUNK;
 // refill threshold: over the compact nodes / over the 128-byte nodes (whose fetches cost more, so that rays refilled
 // together -- they walk the upper tree together and share its lines -- are worth more idle lanes)
 constexpr uint32_t kServiceLanesCompact = RT_SERVICE_LANES, kServiceLanesWide = RT_SERVICE_LANES_WIDE;
+// Camera rays are another matter: consecutive paths are the pixels of 8 x 8 tiles, a run of kRayChunk rays is four
+// whole tiles, and a wave that refills only when all its lanes are done takes exactly one tile at a time -- 64 rays
+// that walk the tree in step.  Measured on the camera rays alone (one bounce): +7 % on the 10 M-triangle scene, +11 %
+// on 1 M triangles, +3 % on the tea set, +1 % on the spheres scene, +0.3 % on Cornell; thresholds between 24 and 64
+// that split tiles over waves (32, 56, 60) are slower than either.  The rays of the first bounce already want the
+// ordinary threshold (16 and 24 equal, 32 / 48 / 64: -2 / -4 / -21 %).
+#ifndef RT_SERVICE_LANES_PRIMARY
+#define RT_SERVICE_LANES_PRIMARY 64
+#endif
+constexpr uint32_t kServiceLanesPrimary = RT_SERVICE_LANES_PRIMARY;
+static_assert(RT_RAY_CHUNK % 64 == 0, "a run of rays is whole tiles");
 
 // Number of different values of `v` among the lanes with `on` (instrumented builds only: one turn per value).
 __device__ __forceinline__ uint32_t wave_distinct(bool on, uint32_t v) {
@@ -148,9 +159,10 @@ template <bool COUNT, bool COMPACT>
 __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     extend_kernel(RtSceneView sc, const float4 *__restrict__ ro, const float4 *__restrict__ rd,
                   const uint32_t *__restrict__ count_ptr, uint32_t n_fixed, float t_min, float t_max,
-                  float2 *__restrict__ hit, uint2 *ovf, uint32_t *head, unsigned long long *counters) {
+                  float2 *__restrict__ hit, uint2 *ovf, uint32_t *head, unsigned long long *counters,
+                  uint32_t service_lanes) {
     __shared__ uint2 s_stack[RT_LDS_STACK * kBlock];
-    constexpr uint32_t kServiceLanes = COMPACT ? kServiceLanesCompact : kServiceLanesWide;
+    const uint32_t kServiceLanes = service_lanes;  // (wave-uniform: idle lanes at which the wave refills)
     const uint32_t n = count_ptr ? *count_ptr : n_fixed;
     const uint32_t lane = threadIdx.x & 63u;
     Stack st;
@@ -700,15 +712,17 @@ struct StageTimer {
 uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
 // `head` is the work counter of this launch; it must be zero when the kernel starts.
+// `coherent`: the rays are camera rays in tile order (see kServiceLanesPrimary).
 int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4 *rd, const uint32_t *count_ptr,
-                  uint32_t n_upper, float t_min, float t_max, bool counted, uint32_t *head) {
+                  uint32_t n_upper, float t_min, float t_max, bool counted, uint32_t *head, bool coherent = false) {
     if (n_upper == 0) return RT_OK;
+    const uint32_t service_lanes = coherent ? kServiceLanesPrimary : (s->compact ? kServiceLanesCompact : kServiceLanesWide);
     uint32_t blocks = std::min(blocks_for(n_upper), s->extend_blocks);
     StageTimer tm(s, stream, 0);
     auto kernel = counted ? (s->compact ? extend_kernel<true, true> : extend_kernel<true, false>)
                           : (s->compact ? extend_kernel<false, true> : extend_kernel<false, false>);
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0, stream, s->view, ro, rd, count_ptr, n_upper, t_min, t_max,
-                       (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head, (unsigned long long *)s->counters.p);
+                       (float2 *)s->hit_a.p, (uint2 *)s->ovf.p, head, (unsigned long long *)s->counters.p, service_lanes);
     RT_HIP(hipGetLastError());
     return RT_OK;
 }
@@ -821,7 +835,7 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
         int cur = 0;
         for (uint32_t b = 0; b < depth; b++) {
             if ((rc = launch_extend(s, stream, st[cur].o, st[cur].d, counts + b, n, kTMin, kTMax, s->counting,
-                                    counts + kCountSlots + b)))
+                                    counts + kCountSlots + b, /*coherent=*/b == 0)))
                 return rc;
             StageTimer tm(s, stream, 1);
             uint32_t blocks = std::min(blocks_for(n), (uint32_t)s->n_cus * 16u);
@@ -1297,7 +1311,7 @@ int rt_closest_hit_batch_noalloc_device(RtScene *s, const float *d_org_dir, floa
     auto kernel = s->compact ? extend_kernel<false, true> : extend_kernel<false, false>;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0,
                        stream, s->view, (const float4 *)ro, (const float4 *)rd, (const uint32_t *)nullptr, m, t_min, t_max,
-                       hit, ovf, head, (unsigned long long *)nullptr);
+                       hit, ovf, head, (unsigned long long *)nullptr, s->compact ? kServiceLanesCompact : kServiceLanesWide);
     hipLaunchKernelGGL(unpack_hits_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream, s->view, (const float2 *)hit,
                        (const float4 *)ro, (const float4 *)rd, m, d_id, d_t, d_normal, d_point);
     RT_HIP(hipGetLastError());
