@@ -11,9 +11,9 @@
 //   accumulate  one lane per pixel: sums that pixel's samples in sample order with
 //               the reference's non-finite scrub and adds the mean to the frame
 //
-// A batch holds all `samples` paths of a run of consecutive pixels, sample-major
-// (slot = sample * pixels + pixel), so the accumulate stage reads coalesced and
-// every radiance sample is written exactly once -- no float atomics anywhere.
+// A batch holds all `samples` paths of a run of consecutive pixels; a path's radiance slot is
+// pixel * samples + sample, and every radiance sample is written exactly once -- no float
+// atomics anywhere.
 // Live-path counts stay on the device; kernels read them and idle lanes exit, so
 // a pass needs no host synchronisation.
 #include <hip/hip_runtime.h>
@@ -60,7 +60,7 @@ struct PathState {
 __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint32_t width, uint32_t height,
                                                            uint32_t spp, uint32_t pass, uint32_t seed, uint32_t p0,
                                                            uint32_t np, uint32_t preview, PathState out,
-                                                           uint32_t *counts, uint32_t n_counts) {
+                                                           uint32_t *counts, uint32_t n_counts, uint32_t wave_samples) {
     uint32_t n = np * spp;
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
@@ -69,7 +69,20 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
         for (uint32_t k = 0; k < n_counts; k++) counts[kCountSlots + k] = 0;  // work counters of the extend launches
     }
     if (i >= n) return;
-    uint32_t s = i / np, j = i - s * np;
+    // Which (sample, pixel offset) path i is.  64 consecutive paths -- a wave of the closest-hit stage, which takes
+    // camera rays 64 at a time -- are `wave_samples` samples (a power of two that divides spp) of 64 / wave_samples
+    // neighbouring pixels: rays through one pixel meet the same nodes and leaves all the way down, so the wave's lanes
+    // stay in step.  (wave_samples = 1: one sample of 64 pixels.)
+    uint32_t s, j;
+    if (wave_samples > 1) {
+        const uint32_t per_group = np * wave_samples;  // paths of one group of wave_samples samples
+        const uint32_t g = i / per_group, r = i - g * per_group;
+        const uint32_t lane = r & 63u;
+        s = g * wave_samples + (lane & (wave_samples - 1u));
+        j = (r >> 6) * (64u / wave_samples) + lane / wave_samples;
+    } else {
+        s = i / np, j = i - s * np;
+    }
     // Consecutive paths take the pixels of 8-row strips column by column (a permutation of the batch's
     // pixel offsets), so the 64 lanes of a wave start on an 8 x 8 tile of the frame rather than on a
     // 64 x 1 line: their rays meet the same nodes.  The radiance slot stays `sample * np + offset`.
@@ -88,7 +101,7 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
     F3 org, dir;
     gen_ray(cam, width, height, x, y, jx, jy, &org, &dir);
     dir = normalized(dir);  // Ray::new (src/ray.rs:10-15)
-    out.o[i] = make_float4(org.x, org.y, org.z, __uint_as_float(s * np + off));
+    out.o[i] = make_float4(org.x, org.y, org.z, __uint_as_float(off * spp + s));  // radiance slot: [pixel][sample]
     out.d[i] = make_float4(dir.x, dir.y, dir.z, 0.0f);
     out.thr[i] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(key));
 }
@@ -490,22 +503,47 @@ __global__ void __launch_bounds__(kBlock) fill_radiance_kernel(float4 *rad, uint
 // ---------------------------------------------------------------------------
 // accumulate: the tail of Renderer::render's per-pixel closure (src/render.rs:203-214)
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock)
+// The radiance buffer is [pixel][sample] (a wave of camera rays writes runs of one pixel's samples, see
+// generate_kernel), and a pixel's sum is sequential (the scrub looks at every partial sum).  One wave per block takes 64
+// pixels: it loads their samples sixteen per pixel at a time as contiguous runs -- every line is read once, whole --
+// into LDS, and each lane then adds up its own pixel's run in sample order.
+#ifndef RT_ACCUM_CHUNK
+#define RT_ACCUM_CHUNK 8
+#endif
+constexpr uint32_t kAccumChunk = RT_ACCUM_CHUNK, kAccumPitch = kAccumChunk + 1;  // (the odd pitch spreads the lanes' rows over the banks)
+__global__ void __launch_bounds__(64)
     accumulate_kernel(const float4 *__restrict__ rad, uint32_t np, uint32_t spp, uint32_t p0, float *accum,
                       int overwrite) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= np) return;
+    __shared__ float4 tile[64 * kAccumPitch];
+    const uint32_t lane = threadIdx.x, base = blockIdx.x * 64u;
+    if (base >= np) return;
+    const uint32_t j = base + lane;
+    const uint32_t live = np - base < 64u ? np - base : 64u;  // pixels of this wave
     float sx = 0.0f, sy = 0.0f, sz = 0.0f;
     const float kInf = __int_as_float(0x7f800000);
-    for (uint32_t s = 0; s < spp; s++) {
-        float4 c = rad[(size_t)s * np + j];
-        sx += c.x;
-        sy += c.y;
-        sz += c.z;
-        if (!(fabsf(sx) < kInf)) sx = 0.0f;
-        if (!(fabsf(sy) < kInf)) sy = 0.0f;
-        if (!(fabsf(sz) < kInf)) sz = 0.0f;
+    if (!overwrite) {
+        for (uint32_t c0 = 0; c0 < spp; c0 += kAccumChunk) {
+            const uint32_t t = spp - c0 < kAccumChunk ? spp - c0 : kAccumChunk;
+            for (uint32_t m = lane; m < live * t; m += 64u) {
+                const uint32_t pp = m / t, ss = m - pp * t;
+                tile[pp * kAccumPitch + ss] = rad[(size_t)(base + pp) * spp + c0 + ss];
+            }
+            __syncthreads();
+            if (lane < live) {
+                for (uint32_t ss = 0; ss < t; ss++) {
+                    const float4 c = tile[lane * kAccumPitch + ss];
+                    sx += c.x;
+                    sy += c.y;
+                    sz += c.z;
+                    if (!(fabsf(sx) < kInf)) sx = 0.0f;
+                    if (!(fabsf(sy) < kInf)) sy = 0.0f;
+                    if (!(fabsf(sz) < kInf)) sz = 0.0f;
+                }
+            }
+            __syncthreads();
+        }
     }
+    if (j >= np) return;
     size_t p = (size_t)(p0 + j) * 3;
     if (overwrite) {
         // Renderer::preview returns the sample itself (src/render.rs:243-259)
@@ -787,6 +825,18 @@ uint64_t default_paths_in_flight(RtScene *s) {
     return budget;
 }
 
+// Samples of one pixel that share a wave of camera rays (see generate_kernel): the largest power of two up to
+// RT_WAVE_SAMPLES that divides spp, provided the batch's pixels fill whole waves that way.
+#ifndef RT_WAVE_SAMPLES
+#define RT_WAVE_SAMPLES 64
+#endif
+uint32_t wave_samples_for(uint32_t spp, uint32_t np) {
+    uint32_t ws = 1;
+    while (ws * 2 <= (uint32_t)RT_WAVE_SAMPLES && spp % (ws * 2) == 0) ws *= 2;
+    while (ws > 1 && np % (64u / ws) != 0) ws /= 2;
+    return ws;
+}
+
 // One pass (or one preview frame) on device memory.
 int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream_t stream, bool preview) {
     int rc = check_params(s, p, d_accum);
@@ -826,7 +876,7 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
             StageTimer tm(s, stream, 2);
             hipLaunchKernelGGL(generate_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, cam, p->width,
                                p->height, spp, p->pass_index, p->seed, (uint32_t)p0, np, preview ? 1u : 0u, st[0],
-                               counts, n_counts);
+                               counts, n_counts, wave_samples_for(spp, np));
         }
         if (depth == 0) {
             // ray_color's loop body never runs: every sample is 1 * 0.01 (src/render.rs:61,83)
@@ -853,7 +903,7 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
         }
         {
             StageTimer tm(s, stream, 2);
-            hipLaunchKernelGGL(accumulate_kernel, dim3(blocks_for(np)), dim3(kBlock), 0, stream, rad, np, spp,
+            hipLaunchKernelGGL(accumulate_kernel, dim3((np + 63u) / 64u), dim3(64), 0, stream, rad, np, spp,
                                (uint32_t)p0, d_accum, preview ? 1 : 0);
             hipLaunchKernelGGL(tally_kernel, dim3(1), dim3(1), 0, stream, counts, depth, (unsigned long long *)s->totals.p);
         }
