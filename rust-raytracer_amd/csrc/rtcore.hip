@@ -83,9 +83,10 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
     } else {
         s = i / np, j = i - s * np;
     }
-    // Consecutive paths take the pixels of 8-row strips column by column (a permutation of the batch's
-    // pixel offsets), so the 64 lanes of a wave start on an 8 x 8 tile of the frame rather than on a
-    // 64 x 1 line: their rays meet the same nodes.  The radiance slot stays `sample * np + offset`.
+    // Consecutive pixels (j) are taken from 8-row strips column by column (a permutation of the batch's pixel
+    // offsets), so the pixels that share a wave are neighbours down a column -- with one sample per wave an 8 x 8
+    // tile of the frame rather than a 64 x 1 line: their rays meet the same nodes.  The radiance slot is
+    // `offset * spp + sample` whatever the order of the paths.
     uint32_t off = j;
     const uint32_t strip = kTileRows * width, whole = np / strip * strip;
     if (j < whole) {
@@ -144,17 +145,19 @@ constexpr uint32_t kRayChunk = RT_RAY_CHUNK;
 // refill threshold: over the compact nodes / over the 128-byte nodes (whose fetches cost more, so that rays refilled
 // together -- they walk the upper tree together and share its lines -- are worth more idle lanes)
 constexpr uint32_t kServiceLanesCompact = RT_SERVICE_LANES, kServiceLanesWide = RT_SERVICE_LANES_WIDE;
-// Camera rays are another matter: consecutive paths are the pixels of 8 x 8 tiles, a run of kRayChunk rays is four
-// whole tiles, and a wave that refills only when all its lanes are done takes exactly one tile at a time -- 64 rays
-// that walk the tree in step.  Measured on the camera rays alone (one bounce): +7 % on the 10 M-triangle scene, +11 %
-// on 1 M triangles, +3 % on the tea set, +1 % on the spheres scene, +0.3 % on Cornell; thresholds between 24 and 64
-// that split tiles over waves (32, 56, 60) are slower than either.  The rays of the first bounce already want the
-// ordinary threshold (16 and 24 equal, 32 / 48 / 64: -2 / -4 / -21 %).
+// Camera rays are another matter: every 64 consecutive paths are a group of neighbouring rays (generate_kernel: the
+// samples of a few neighbouring pixels, or one sample of an 8 x 8 tile), a run of kRayChunk rays is four whole
+// groups, and a wave that refills only when all its lanes are done takes exactly one group at a time -- 64 rays
+// that walk the tree in step.  Measured on the camera rays alone (one bounce, 8 x 8 tiles): +7 % on the 10 M-triangle
+// scene, +11 % on 1 M triangles, +3 % on the tea set, +1 % on the spheres scene, +0.3 % on Cornell; thresholds
+// between 24 and 64 that split groups over waves (32, 56, 60) are slower than either, and 64 stays the best with the
+// samples of a pixel in one wave.  The rays of the first bounce already want the ordinary threshold (16 and 24
+// equal, 32 / 48 / 64: -2 / -4 / -21 %).
 #ifndef RT_SERVICE_LANES_PRIMARY
 #define RT_SERVICE_LANES_PRIMARY 64
 #endif
 constexpr uint32_t kServiceLanesPrimary = RT_SERVICE_LANES_PRIMARY;
-static_assert(RT_RAY_CHUNK % 64 == 0, "a run of rays is whole tiles");
+static_assert(RT_RAY_CHUNK % 64 == 0, "a run of rays is whole groups of 64");
 
 // Number of different values of `v` among the lanes with `on` (instrumented builds only: one turn per value).
 __device__ __forceinline__ uint32_t wave_distinct(bool on, uint32_t v) {
@@ -750,7 +753,7 @@ struct StageTimer {
 uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
 // `head` is the work counter of this launch; it must be zero when the kernel starts.
-// `coherent`: the rays are camera rays in tile order (see kServiceLanesPrimary).
+// `coherent`: the rays are camera rays in the order generate_kernel makes them (see kServiceLanesPrimary).
 int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4 *rd, const uint32_t *count_ptr,
                   uint32_t n_upper, float t_min, float t_max, bool counted, uint32_t *head, bool coherent = false) {
     if (n_upper == 0) return RT_OK;
