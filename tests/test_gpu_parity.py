@@ -217,6 +217,14 @@ def test_ray_count_matches_oracle(pkg, oracle):
         (64, 48, 33, 8, 1000),  # batches that split pixels' sample runs (33 spp, 1000 paths per batch)
         (17, 13, 4, 50, 1),     # deep paths, the smallest batch
         (640, 3, 2, 8, 0),      # wide and flat
+        # which camera rays share a wave depends on spp and on the batch's pixel count (samples of a pixel go into one
+        # wave when both divide evenly): every combination must leave the frame as it is
+        (32, 17, 16, 4, 0),     # 16 samples of 4 pixels per wave
+        (31, 17, 16, 4, 0),     # ... and a pixel count that forbids it
+        (40, 30, 64, 3, 0),     # one pixel's 64 samples per wave
+        (40, 30, 128, 2, 5000), # 128 spp in batches of 39 pixels
+        (36, 9, 48, 3, 0),      # 48 spp: 16 samples of 4 pixels, three groups
+        (33, 9, 48, 3, 700),    # ... in batches of 14 pixels (8 samples of 8 pixels would need a multiple of 8)
     ],
 )
 def test_render_pass_parameter_edges(pkg, oracle, W, H, spp, bounces, batch):
