@@ -40,7 +40,12 @@ using namespace rtd;
 namespace {
 
 constexpr int kBlock = 256;
-constexpr uint32_t kCountSlots = 1024;  // live-path counts [0, kCountSlots), extend work counters [kCountSlots, 2 kCountSlots)
+constexpr uint32_t kCountSlots = 1024;  // live-path counts [0, kCountSlots), then the work counters of the extend launches
+// A launch's rays are dealt out from kWorkShares counters, each in a 128-byte line of its own (see extend_kernel)
+#ifndef RT_WORK_SHARES
+#define RT_WORK_SHARES 16
+#endif
+constexpr uint32_t kWorkShares = RT_WORK_SHARES, kWorkStride = 32, kWorkWords = kWorkShares * kWorkStride;
 #ifndef RT_TILE_ROWS
 #define RT_TILE_ROWS 8
 #endif
@@ -65,8 +70,7 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         counts[0] = n;
-        for (uint32_t k = 1; k < n_counts; k++) counts[k] = 0;
-        for (uint32_t k = 0; k < n_counts; k++) counts[kCountSlots + k] = 0;  // work counters of the extend launches
+        for (uint32_t k = 1; k < n_counts; k++) counts[k] = 0;  // (the extend launches' work counters are cleared by the host's memset)
     }
     if (i >= n) return;
     // Which (sample, pixel offset) path i is.  64 consecutive paths -- a wave of the closest-hit stage, which takes
@@ -112,13 +116,13 @@ __global__ void __launch_bounds__(kBlock) generate_kernel(RtDevCamera cam, uint3
 // hit = (t, visit rank)   rank -1 = miss; the consumer completes the HitRecord (barycentrics,
 // normal, material, primitive id) with finish_hit, where all lanes of a wave are busy
 // ---------------------------------------------------------------------------
-// Persistent waves: a wave reserves runs of kRayChunk consecutive ray indices from a global
-// counter and hands them to its lanes; a lane that has finished its ray parks its result, and
+// Persistent waves: a wave reserves runs of kRayChunk consecutive ray indices from the counter of
+// its share of the launch (see the kernel) and hands them to its lanes; a lane that has finished its ray parks its result, and
 // once kServiceLanes lanes are parked or empty the wave writes the parked results and refills
 // those lanes, so the lanes of a wave work on different rays at different depths instead of
 // idling until the slowest ray of a fixed group of 64 is done.
 #ifndef RT_RAY_CHUNK
-#define RT_RAY_CHUNK 256
+#define RT_RAY_CHUNK 128
 #endif
 #ifndef RT_SERVICE_LANES
 #define RT_SERVICE_LANES 24
@@ -146,7 +150,7 @@ constexpr uint32_t kRayChunk = RT_RAY_CHUNK;
 // together -- they walk the upper tree together and share its lines -- are worth more idle lanes)
 constexpr uint32_t kServiceLanesCompact = RT_SERVICE_LANES, kServiceLanesWide = RT_SERVICE_LANES_WIDE;
 // Camera rays are another matter: every 64 consecutive paths are a group of neighbouring rays (generate_kernel: the
-// samples of a few neighbouring pixels, or one sample of an 8 x 8 tile), a run of kRayChunk rays is four whole
+// samples of a few neighbouring pixels, or one sample of an 8 x 8 tile), a run of kRayChunk rays is whole
 // groups, and a wave that refills only when all its lanes are done takes exactly one group at a time -- 64 rays
 // that walk the tree in step.  Measured on the camera rays alone (one bounce, 8 x 8 tiles): +7 % on the 10 M-triangle
 // scene, +11 % on 1 M triangles, +3 % on the tea set, +1 % on the spheres scene, +0.3 % on Cornell; thresholds
@@ -200,6 +204,17 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     bool no_more = false;                    // wave-uniform: the global counter ran past n
     auto lanes = [](bool p) { return (unsigned long long)__builtin_amdgcn_ballot_w64(p); };
 
+    // Work distribution.  One global counter takes about 84 reservations per microsecond from the whole chip, which
+    // runs of 256 rays turn into a ceiling of ~21 Grays/s (scenes with cheap rays sat at it: Cornell 19.4 Grays/s in
+    // this stage with one counter, 30 with these) and which forbids the shorter runs that expensive rays do better
+    // with.  So the launch's rays are cut into kWorkShares contiguous shares, each with a counter in a line of its
+    // own; a wave starts on the share of its block's number modulo kWorkShares -- blocks are dealt to the eight XCDs
+    // in turn, so a share's rays, neighbours in the frame, mostly meet in one XCD's L2 -- and moves on to the next
+    // share when its own has run out (every share is drained by whoever gets there; a wave never goes back).
+    // Measured: 8 / 16 / 32 shares and runs of 64 / 128 / 192 / 256 rays; 16 x 128 is the best or within 2 % of it on
+    // every configuration.
+    const uint32_t per_share = ((n + kWorkShares * 64u - 1u) / (kWorkShares * 64u)) * 64u;  // whole groups of 64 rays
+    uint32_t share = blockIdx.x % kWorkShares, shares_left = kWorkShares;                  // wave-uniform
     const long long loop_t0 = COUNT ? clock64() : 0;
     for (;;) {
         const uint32_t n_idle = (uint32_t)__popcll(lanes(state >= kParked));
@@ -216,12 +231,24 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
                 const uint32_t want = (uint32_t)__popcll(empty_mask);
                 if (want < kServiceLanes) break;
                 if (chunk_next == chunk_end) {
-                    uint32_t b = 0;
-                    if (lane == 0) b = atomicAdd(head, kRayChunk);
-                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-                    chunk_next = b < n ? b : n;
-                    chunk_end = (b + kRayChunk) < n ? (b + kRayChunk) : n;
-                    if (b >= n) {
+                    // a run from the share this wave is on; a share that has run out sends the wave on to the next one
+                    bool got = false;
+                    while (shares_left != 0u) {
+                        const uint32_t lo = share * per_share < n ? share * per_share : n;
+                        const uint32_t size = n - lo < per_share ? n - lo : per_share;
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(head + share * kWorkStride, kRayChunk);
+                        b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                        if (b < size) {
+                            chunk_next = lo + b;
+                            chunk_end = lo + ((b + kRayChunk) < size ? (b + kRayChunk) : size);
+                            got = true;
+                            break;
+                        }
+                        share = (share + 1u) % kWorkShares;
+                        shares_left--;
+                    }
+                    if (!got) {
                         no_more = true;
                         break;
                     }
@@ -702,7 +729,7 @@ int ensure_work(RtScene *s, uint64_t paths) {
     }
     if ((rc = s->hit_a.ensure(paths * 8))) return rc;
     if ((rc = s->rad.ensure(paths * 16))) return rc;
-    if ((rc = s->counts.ensure(2 * kCountSlots * sizeof(uint32_t)))) return rc;
+    if ((rc = s->counts.ensure(((size_t)kCountSlots + (size_t)kCountSlots * kWorkWords) * sizeof(uint32_t)))) return rc;
     if (!s->totals.p) {
         if ((rc = s->totals.ensure(64))) return rc;
         RT_HIP(hipMemset(s->totals.p, 0, 64));
@@ -753,7 +780,7 @@ struct StageTimer {
 
 uint32_t blocks_for(uint64_t n) { return (uint32_t)((n + kBlock - 1) / kBlock); }
 
-// `head` is the work counter of this launch; it must be zero when the kernel starts.
+// `head` points at the kWorkWords words of this launch's work counters; they must be zero when the kernel starts.
 // `coherent`: the rays are camera rays in the order generate_kernel makes them (see kServiceLanesPrimary).
 int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4 *rd, const uint32_t *count_ptr,
                   uint32_t n_upper, float t_min, float t_max, bool counted, uint32_t *head, bool coherent = false) {
@@ -771,12 +798,12 @@ int launch_extend(RtScene *s, hipStream_t stream, const float4 *ro, const float4
 
 // ---- work memory of the entry point that allocates nothing (rt_closest_hit_batch_noalloc_device) ----
 // One array per GPU, held from the moment the library's code is loaded on that GPU until the process ends.
-// Layout: [0, 256) the launch's work counter; packed ray origins, packed directions, hits for kNoAllocMaxRays
+// Layout: [0, kScratchRo) the launch's work counters; packed ray origins, packed directions, hits for kNoAllocMaxRays
 // rays; the rest is the overflow area of the traversal stacks.  In host code the array's NAME is not a device
 // address: the address on each device comes from hipGetSymbolAddress (scratch_base) and only that goes to kernels.
 constexpr size_t kNoAllocMaxRays = 1u << 18;
 constexpr size_t kScratchBytes = 64ull << 20;
-constexpr size_t kScratchRo = 256, kScratchRd = kScratchRo + kNoAllocMaxRays * 16, kScratchHit = kScratchRd + kNoAllocMaxRays * 16,
+constexpr size_t kScratchRo = kWorkWords * sizeof(uint32_t), kScratchRd = kScratchRo + kNoAllocMaxRays * 16, kScratchHit = kScratchRd + kNoAllocMaxRays * 16,
                  kScratchOvf = kScratchHit + kNoAllocMaxRays * 8;
 static_assert(kScratchOvf % 256 == 0 && kScratchOvf < kScratchBytes, "scratch layout");
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
@@ -869,6 +896,7 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
     const uint32_t n_counts = depth + 2;
     if (n_counts > kCountSlots) return fail(RT_ERR_INVALID_ARGUMENT, "max_bounce too large");
     uint32_t *counts = (uint32_t *)s->counts.p;
+    uint32_t *work = counts + kCountSlots;  // kWorkWords per extend launch
     PathState st[2];
     for (int k = 0; k < 2; k++) st[k] = PathState{(float4 *)s->st_o[k].p, (float4 *)s->st_d[k].p, (float4 *)s->st_thr[k].p};
     float4 *rad = (float4 *)s->rad.p;
@@ -878,6 +906,7 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
         const uint32_t n = np * spp;
         {
             StageTimer tm(s, stream, 2);
+            if (depth) RT_HIP(hipMemsetAsync(work, 0, (size_t)depth * kWorkWords * sizeof(uint32_t), stream));
             hipLaunchKernelGGL(generate_kernel, dim3(blocks_for(n)), dim3(kBlock), 0, stream, cam, p->width,
                                p->height, spp, p->pass_index, p->seed, (uint32_t)p0, np, preview ? 1u : 0u, st[0],
                                counts, n_counts, wave_samples_for(spp, np));
@@ -889,7 +918,7 @@ int render_device(RtScene *s, const RtRenderParams *p, float *d_accum, hipStream
         int cur = 0;
         for (uint32_t b = 0; b < depth; b++) {
             if ((rc = launch_extend(s, stream, st[cur].o, st[cur].d, counts + b, n, kTMin, kTMax, s->counting,
-                                    counts + kCountSlots + b, /*coherent=*/b == 0)))
+                                    work + (size_t)b * kWorkWords, /*coherent=*/b == 0)))
                 return rc;
             StageTimer tm(s, stream, 1);
             uint32_t blocks = std::min(blocks_for(n), (uint32_t)s->n_cus * 16u);
@@ -1305,8 +1334,8 @@ static int closest_hit_device(RtScene *s, const float *d_org_dir, float t_min, f
             StageTimer tm(s, stream, 2);
             hipLaunchKernelGGL(pack_rays_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream, d_org_dir + off * 6, m, ro, rd);
         }
-        uint32_t *head = (uint32_t *)s->counts.p + 2 * kCountSlots - 1;
-        RT_HIP(hipMemsetAsync(head, 0, sizeof(uint32_t), stream));
+        uint32_t *head = (uint32_t *)s->counts.p + kCountSlots + (size_t)(kCountSlots - 1) * kWorkWords;  // the last launch slot
+        RT_HIP(hipMemsetAsync(head, 0, kWorkWords * sizeof(uint32_t), stream));
         if ((rc = launch_extend(s, stream, ro, rd, nullptr, m, t_min, t_max, counted, head))) return rc;
         {
             StageTimer tm(s, stream, 2);
@@ -1360,7 +1389,7 @@ int rt_closest_hit_batch_noalloc_device(RtScene *s, const float *d_org_dir, floa
     float2 *hit = (float2 *)(base + kScratchHit);
     uint2 *ovf = (uint2 *)(base + kScratchOvf);
     const uint32_t m = (uint32_t)n;
-    RT_HIP(hipMemsetAsync(head, 0, 256, stream));  // the array keeps the last call's contents
+    RT_HIP(hipMemsetAsync(head, 0, kScratchRo, stream));  // the array keeps the last call's contents
     hipLaunchKernelGGL(pack_rays_kernel, dim3(blocks_for(m)), dim3(kBlock), 0, stream, d_org_dir, m, ro, rd);
     auto kernel = s->compact ? extend_kernel<false, true> : extend_kernel<false, false>;
     hipLaunchKernelGGL(kernel, dim3(blocks), dim3(kBlock), 0,
