@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(kBlock, RT_EXTEND_WAVES)
     uint32_t state = kEmpty;
     int32_t ray_i = 0;                       // ray this lane works on (state < kEmpty)
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform: the reserved run of ray indices
-    bool no_more = false;                    // wave-uniform: the global counter ran past n
+    bool no_more = false;                    // wave-uniform: every share of the launch has run out
     auto lanes = [](bool p) { return (unsigned long long)__builtin_amdgcn_ballot_w64(p); };
 
     // Work distribution.  One global counter takes about 84 reservations per microsecond from the whole chip, which
