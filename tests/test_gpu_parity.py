@@ -130,6 +130,15 @@ def test_degenerate_rays(pkg, oracle):
     check_hits(pkg, oracle, d, rays, expect_hits=False)
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 1023, 1025, 2049, 16 * 128 + 1, 50_001])
+def test_batch_sizes_around_the_work_shares(pkg, oracle, n):
+    """A launch's rays are dealt out in sixteen contiguous shares of whole groups of 64 rays, in runs of 128: batches
+    smaller than a group, smaller than the shares, with ragged last shares and last runs must come back complete."""
+    d = pkg.scenes.rtiow(seed=3)
+    rays = camera_like_rays(n, (13, 2, 3), (-6, 0, -6), (6, 2, 6), 100 + n)
+    check_hits(pkg, oracle, d, rays, expect_hits=n > 100)
+
+
 def test_t_range_bounds(pkg, oracle):
     """Caller-supplied t_min / t_max, including hits exactly at t_max (inclusive for triangles and box entries)."""
     S = pkg.SceneDescription()
